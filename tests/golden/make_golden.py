@@ -85,7 +85,7 @@ class DrawLog:
 
 
 def np32(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()      # copy: state_dict tensors alias live parameters
 
 
 def save(name, **arrays):
