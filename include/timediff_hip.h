@@ -1,0 +1,195 @@
+/*
+ * timediff_hip.h -- C ABI of libtimediff_hip.so: the MI355X (gfx950) implementation of TimeDiff's
+ * ETDiff hot path (denoiser forward/backward, mixed-diffusion forward noising, reverse update,
+ * loss, T-step sampler).
+ *
+ * The reference (MuhangTian/TimeDiff) is pure Python and has no FFI of its own; each entry point
+ * cites the Python symbol (file:line under the reference tree) whose arithmetic it replaces.  The
+ * host-side mirror that keeps the reference's class interfaces lives in the timediff_amd Python package and
+ * binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - tensors are dense row-major in the reference's (torch) layouts; weights are read in torch's
+ *     native layout (LSTM gate rows i,f,g,o; GRU gate rows r,z,n);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *     enqueues work, none synchronises, allocates or frees device memory: scratch comes in through
+ *     the `workspace` arguments sized by the matching *_bytes() query;
+ *   - return value: TD_OK or an error code; td_last_error() returns the message (thread-local).
+ */
+#ifndef TIMEDIFF_HIP_H
+#define TIMEDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TD_OK = 0, TD_ERR_INVALID = 1, TD_ERR_HIP = 2, TD_ERR_UNSUPPORTED = 3 };
+
+int td_version(void);
+const char *td_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Denoiser: models/ETDiff/blocks.py RNN (:300-341) = time_emb (:324-329, SinusoidalPosEmb :12-24)
+ * + RNNBlock (:264-297: nn.LSTM / nn.GRU, LayerNorm, FiLM) + fc.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct td_rnn_config {
+    int32_t c_in;      /* RNN(input_channels)                       */
+    int32_t hidden;    /* RNN(hidden_channels)                      */
+    int32_t c_out;     /* RNN(output_channels)                      */
+    int32_t layers;    /* RNN(layers)                               */
+    int32_t dirs;      /* 2 if bidirectional else 1                 */
+    int32_t gru;       /* model == "gru"                            */
+    int32_t embed_dim; /* RNN(embed_dim), SinusoidalPosEmb width    */
+    int32_t time_dim;  /* RNN(time_dim)                             */
+} td_rnn_config;
+
+/* Index of each tensor in the `misc_host` pointer table (state_dict names in comments). */
+enum {
+    TD_TE_W1 = 0, /* time_emb.1.weight      (time_dim, embed_dim) */
+    TD_TE_B1,     /* time_emb.1.bias                                */
+    TD_TE_W2,     /* time_emb.3.weight      (time_dim, time_dim)  */
+    TD_TE_B2,     /* time_emb.3.bias                                */
+    TD_FILM_W,    /* rnn.time_mlp.1.weight  (2*D*H, time_dim)     */
+    TD_FILM_B,    /* rnn.time_mlp.1.bias                            */
+    TD_LN_W,      /* rnn.norm.weight        (D*H)                 */
+    TD_LN_B,      /* rnn.norm.bias                                  */
+    TD_FC_W,      /* fc.weight              (c_out, D*H)          */
+    TD_FC_B,      /* fc.bias                                        */
+    TD_MISC_COUNT
+};
+
+/* Bytes of the MFMA-ordered bf16 copy of the recurrent weights (a derived cache; rebuild after
+ * every optimizer step) and of the forward workspace for a (B, L) batch. */
+size_t td_rnn_packed_bytes(const td_rnn_config *cfg);
+size_t td_rnn_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
+
+/* layer_weights_host[(layer*dirs + dir)*4 + {0: weight_ih, 1: weight_hh, 2: bias_ih, 3: bias_hh}]
+ * (rnn.rnn.weight_ih_l{k}[_reverse] ...): host array of device pointers to fp32 tensors. */
+int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const *layer_weights_host, void *packed, void *stream);
+
+/* blocks.py:338 + :285: film[i, :] = Linear(SiLU(time_emb(t[i]))) for i < n_t; film is (n_t, 2*D*H):
+ * scale = film[:, :D*H], shift = film[:, D*H:].  temb_out (n_t, time_dim) may be NULL. */
+int td_rnn_time_film(const td_rnn_config *cfg, const float *const *misc_host, const int64_t *t, int32_t n_t,
+                     float *film, float *temb_out, void *stream);
+
+/* blocks.py:333-341 after the time embedding: y = fc(FiLM(LayerNorm(BRNN(x^T))))^T.
+ *   x: (B, c_in, L) fp32    y: (B, c_out, L) fp32
+ *   film: rows of 2*D*H; row used for batch element b is
+ *         film_row == NULL ? b * (film_rows > 1) : film_row[0]   (device scalar: the sampler's step counter)
+ * Recurrent GEMMs run on bf16 MFMA with fp32 accumulate, fp32 cell state and an fp32-equivalent
+ * (split-bf16) first-layer input projection. */
+int td_rnn_forward(const td_rnn_config *cfg, const void *packed, const float *const *misc_host, const float *x,
+                   const float *film, int32_t film_rows, const int32_t *film_row, int32_t batch, int32_t seq_len,
+                   float *y, void *workspace, void *stream);
+
+/* Parity/debug: the last layer's output (what nn.LSTM returns, blocks.py:289-290) as (B, L, D*H)
+ * fp32, decoded from the workspace left by td_rnn_forward. */
+int td_rnn_read_hidden(const td_rnn_config *cfg, const void *workspace, int32_t batch, int32_t seq_len, float *hidden,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Mixed diffusion: models/ETDiff/mixed_diffusion.py MixedDiffusion (:68-454); n_cat = 0 gives
+ * models/ETDiff/gaussian_diffusion.py GaussianDiffusion.
+ * ------------------------------------------------------------------------------------------ */
+enum { /* rows of the (TD_TAB_COUNT, T) fp32 `tables` array = buffers registered at mixed_diffusion.py:113-158 */
+    TD_TAB_SQRT_AC = 0,      /* sqrt_alphas_cumprod            */
+    TD_TAB_SQRT_1M_AC,       /* sqrt_one_minus_alphas_cumprod  */
+    TD_TAB_SQRT_RECIP_AC,    /* sqrt_recip_alphas_cumprod      */
+    TD_TAB_SQRT_RECIPM1_AC,  /* sqrt_recipm1_alphas_cumprod    */
+    TD_TAB_POST_C1,          /* posterior_mean_coef1           */
+    TD_TAB_POST_C2,          /* posterior_mean_coef2           */
+    TD_TAB_POST_LOGVAR,      /* posterior_log_variance_clipped */
+    TD_TAB_LOG_ALPHA,        /* log_alpha                      */
+    TD_TAB_LOG_1M_ALPHA,     /* log_1_min_alpha                */
+    TD_TAB_LOG_CUM_ALPHA,    /* log_cumprod_alpha              */
+    TD_TAB_LOG_1M_CUM_ALPHA, /* log_1_min_cumprod_alpha        */
+    TD_TAB_COUNT
+};
+
+#define TD_MAX_CAT 32 /* discrete variables per model */
+
+typedef struct td_diffusion_config {
+    int32_t n_num;               /* continuous channels                                   */
+    int32_t n_cat;               /* discrete variables                                    */
+    int32_t seq_len;             /* L                                                     */
+    int32_t timesteps;           /* T                                                     */
+    int32_t num_classes[TD_MAX_CAT]; /* K_i (categorical_num_classes)                     */
+    int32_t num_index[TD_MAX_CAT * 2]; /* numerical_features_indices (dataset channel)    */
+    int32_t cat_index[TD_MAX_CAT];   /* categorical_features_indices (dataset channel)    */
+    int32_t data_channels;       /* channels of a dataset tensor / of sample()'s result   */
+    const float *tables;         /* device, (TD_TAB_COUNT, T)                             */
+} td_diffusion_config;
+
+/* Noise sources.  A NULL `noise` / `uniforms` pointer selects the in-kernel Philox4x32-10 stream
+ * (seed, patient = patient0 + b, position l, tag); the layout of the counters is in
+ * timediff_amd/csrc/common.h and oracle/etdiff_oracle.c.  Parity runs pass the reference's draws:
+ *   noise (B, n_num, L), uniforms (B, sum K, L)   [draw order: SURVEY.md section 8c]. */
+typedef struct td_rng {
+    uint64_t seed;
+    uint32_t patient0;
+    uint32_t tag;
+} td_rng;
+
+/* mixed_diffusion.py:403-409 + :375-387: normalize_numericals, gauss_q_sample (:240-248),
+ * index_to_log_onehot (:44-51), cat_q_sample (:313-316), concatenation.
+ *   data: (B, data_channels, L) fp32, numericals in [0,1], discrete channels hold class ids
+ *   t: (B) int64.   Outputs: x_in (B, n_num + sum K, L), x0_idx / xt_idx (B, n_cat, L) uint8,
+ *   noise_out (B, n_num, L): the epsilon actually used (needed by the loss). */
+int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, const float *data, const int64_t *t,
+                      const float *noise, const float *uniforms, td_rng rng, float *x_in, uint8_t *x0_idx,
+                      uint8_t *xt_idx, float *noise_out, void *stream);
+
+/* mixed_diffusion.py:390-401: cat_loss (:358-362, :341-356, :330-339) / n_cat and gauss_loss (:364-368)
+ * plus the analytic gradient w.r.t. model_out.  loss: device scalar; grad: (B, n_num + sum K, L) or NULL.
+ * `scale` multiplies the gradient (1/gradient_accumulate_every, et_diff.py:234).
+ * workspace: td_mixed_loss_workspace_bytes(batch). */
+size_t td_mixed_loss_workspace_bytes(const td_diffusion_config *cfg, int32_t batch);
+int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *noise,
+                  const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t, float loss_lambda, float scale,
+                  float *loss, float *grad, void *workspace, void *stream);
+
+/* mixed_diffusion.py:429-435: z_T ~ N(0, I) (B, n_num, L) and the uniform categorical prior as class ids. */
+int td_sample_prior(const td_diffusion_config *cfg, int32_t batch, const float *noise, const float *uniforms,
+                    td_rng rng, float *z, uint8_t *idx, void *stream);
+
+/* mixed_diffusion.py:439 with :44-51: denoiser input cat([z, log_onehot(idx)]) as (B, n_num + sum K, L). */
+int td_build_denoiser_input(const td_diffusion_config *cfg, int32_t batch, const float *z, const uint8_t *idx,
+                            float *x_in, void *stream);
+
+/* One reverse update in place: gauss_p_sample (mixed_diffusion.py:412-423 -> :196-238) and
+ * cat_p_sample (:307-311 -> :274-305, :318-328).  The step index is `t_host` when t_dev == NULL,
+ * else the device scalar t_dev[0] (hipGraph replay).  rng.tag is ignored: the tag is the step index. */
+int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t batch, const float *model_out, float *z,
+                          uint8_t *idx, int32_t t_host, const int32_t *t_dev, const float *noise,
+                          const float *uniforms, td_rng rng, void *stream);
+
+/* mixed_diffusion.py:448-453 (+ :59-66, :173-179, utils.py:95-99): (z+1)/2 and class ids scattered to
+ * dataset channel order, (B, data_channels, L) fp32. */
+int td_decode_samples(const td_diffusion_config *cfg, int32_t batch, const float *z, const uint8_t *idx,
+                      float *samples, void *stream);
+
+/* The whole reverse chain, mixed_diffusion.py:425-454 (and gaussian_diffusion.py:133-152 when n_cat = 0):
+ * prior draw, T x (denoiser forward + reverse update) replayed as a captured hipGraph whose kernels
+ * read the step index from a device counter, decode.  No host round trip inside the chain.
+ *   film_table: (T, 2*D*H) from td_rnn_time_film(t = 0..T-1)
+ *   noise_host_or_null / uniforms: optional externally supplied draws, (T+1, ...) in loop order with
+ *   index 0 = prior, index 1 + s = step t = T-1-s; NULL = Philox.
+ *   samples: (B, data_channels, L) fp32 on the device. */
+size_t td_sample_chain_workspace_bytes(const td_rnn_config *rnn, const td_diffusion_config *cfg, int32_t batch);
+int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_config *cfg, const void *packed,
+                    const float *const *misc_host, const float *film_table, int32_t batch, const float *noise,
+                    const float *uniforms, td_rng rng, int32_t use_graph, float *samples, void *workspace,
+                    void *stream);
+
+/* Releases the cached step graph of td_sample_chain (waits for the stream it was launched on).
+ * No counterpart in the reference. */
+int td_sample_chain_release(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMEDIFF_HIP_H */
