@@ -27,10 +27,16 @@
 extern "C" {
 #endif
 
+#if defined(__GNUC__)
+#define TD_API __attribute__((visibility("default")))
+#else
+#define TD_API
+#endif
+
 enum { TD_OK = 0, TD_ERR_INVALID = 1, TD_ERR_HIP = 2, TD_ERR_UNSUPPORTED = 3 };
 
-int td_version(void);
-const char *td_last_error(void);
+TD_API int td_version(void);
+TD_API const char *td_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * Denoiser: models/ETDiff/blocks.py RNN (:300-341) = time_emb (:324-329, SinusoidalPosEmb :12-24)
@@ -64,16 +70,16 @@ enum {
 
 /* Bytes of the MFMA-ordered bf16 copy of the recurrent weights (a derived cache; rebuild after
  * every optimizer step) and of the forward workspace for a (B, L) batch. */
-size_t td_rnn_packed_bytes(const td_rnn_config *cfg);
-size_t td_rnn_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
+TD_API size_t td_rnn_packed_bytes(const td_rnn_config *cfg);
+TD_API size_t td_rnn_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
 
 /* layer_weights_host[(layer*dirs + dir)*4 + {0: weight_ih, 1: weight_hh, 2: bias_ih, 3: bias_hh}]
  * (rnn.rnn.weight_ih_l{k}[_reverse] ...): host array of device pointers to fp32 tensors. */
-int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const *layer_weights_host, void *packed, void *stream);
+TD_API int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const *layer_weights_host, void *packed, void *stream);
 
 /* blocks.py:338 + :285: film[i, :] = Linear(SiLU(time_emb(t[i]))) for i < n_t; film is (n_t, 2*D*H):
  * scale = film[:, :D*H], shift = film[:, D*H:].  temb_out (n_t, time_dim) may be NULL. */
-int td_rnn_time_film(const td_rnn_config *cfg, const float *const *misc_host, const int64_t *t, int32_t n_t,
+TD_API int td_rnn_time_film(const td_rnn_config *cfg, const float *const *misc_host, const int64_t *t, int32_t n_t,
                      float *film, float *temb_out, void *stream);
 
 /* blocks.py:333-341 after the time embedding: y = fc(FiLM(LayerNorm(BRNN(x^T))))^T.
@@ -82,13 +88,13 @@ int td_rnn_time_film(const td_rnn_config *cfg, const float *const *misc_host, co
  *         film_row == NULL ? b * (film_rows > 1) : film_row[0]   (device scalar: the sampler's step counter)
  * Recurrent GEMMs run on bf16 MFMA with fp32 accumulate, fp32 cell state and an fp32-equivalent
  * (split-bf16) first-layer input projection. */
-int td_rnn_forward(const td_rnn_config *cfg, const void *packed, const float *const *misc_host, const float *x,
+TD_API int td_rnn_forward(const td_rnn_config *cfg, const void *packed, const float *const *misc_host, const float *x,
                    const float *film, int32_t film_rows, const int32_t *film_row, int32_t batch, int32_t seq_len,
                    float *y, void *workspace, void *stream);
 
 /* Parity/debug: the last layer's output (what nn.LSTM returns, blocks.py:289-290) as (B, L, D*H)
  * fp32, decoded from the workspace left by td_rnn_forward. */
-int td_rnn_read_hidden(const td_rnn_config *cfg, const void *workspace, int32_t batch, int32_t seq_len, float *hidden,
+TD_API int td_rnn_read_hidden(const td_rnn_config *cfg, const void *workspace, int32_t batch, int32_t seq_len, float *hidden,
                        void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -139,7 +145,7 @@ typedef struct td_rng {
  *   data: (B, data_channels, L) fp32, numericals in [0,1], discrete channels hold class ids
  *   t: (B) int64.   Outputs: x_in (B, n_num + sum K, L), x0_idx / xt_idx (B, n_cat, L) uint8,
  *   noise_out (B, n_num, L): the epsilon actually used (needed by the loss). */
-int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, const float *data, const int64_t *t,
+TD_API int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, const float *data, const int64_t *t,
                       const float *noise, const float *uniforms, td_rng rng, float *x_in, uint8_t *x0_idx,
                       uint8_t *xt_idx, float *noise_out, void *stream);
 
@@ -147,29 +153,29 @@ int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, const float
  * plus the analytic gradient w.r.t. model_out.  loss: device scalar; grad: (B, n_num + sum K, L) or NULL.
  * `scale` multiplies the gradient (1/gradient_accumulate_every, et_diff.py:234).
  * workspace: td_mixed_loss_workspace_bytes(batch). */
-size_t td_mixed_loss_workspace_bytes(const td_diffusion_config *cfg, int32_t batch);
-int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *noise,
+TD_API size_t td_mixed_loss_workspace_bytes(const td_diffusion_config *cfg, int32_t batch);
+TD_API int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *noise,
                   const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t, float loss_lambda, float scale,
                   float *loss, float *grad, void *workspace, void *stream);
 
 /* mixed_diffusion.py:429-435: z_T ~ N(0, I) (B, n_num, L) and the uniform categorical prior as class ids. */
-int td_sample_prior(const td_diffusion_config *cfg, int32_t batch, const float *noise, const float *uniforms,
+TD_API int td_sample_prior(const td_diffusion_config *cfg, int32_t batch, const float *noise, const float *uniforms,
                     td_rng rng, float *z, uint8_t *idx, void *stream);
 
 /* mixed_diffusion.py:439 with :44-51: denoiser input cat([z, log_onehot(idx)]) as (B, n_num + sum K, L). */
-int td_build_denoiser_input(const td_diffusion_config *cfg, int32_t batch, const float *z, const uint8_t *idx,
+TD_API int td_build_denoiser_input(const td_diffusion_config *cfg, int32_t batch, const float *z, const uint8_t *idx,
                             float *x_in, void *stream);
 
 /* One reverse update in place: gauss_p_sample (mixed_diffusion.py:412-423 -> :196-238) and
  * cat_p_sample (:307-311 -> :274-305, :318-328).  The step index is `t_host` when t_dev == NULL,
  * else the device scalar t_dev[0] (hipGraph replay).  rng.tag is ignored: the tag is the step index. */
-int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t batch, const float *model_out, float *z,
+TD_API int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t batch, const float *model_out, float *z,
                           uint8_t *idx, int32_t t_host, const int32_t *t_dev, const float *noise,
                           const float *uniforms, td_rng rng, void *stream);
 
 /* mixed_diffusion.py:448-453 (+ :59-66, :173-179, utils.py:95-99): (z+1)/2 and class ids scattered to
  * dataset channel order, (B, data_channels, L) fp32. */
-int td_decode_samples(const td_diffusion_config *cfg, int32_t batch, const float *z, const uint8_t *idx,
+TD_API int td_decode_samples(const td_diffusion_config *cfg, int32_t batch, const float *z, const uint8_t *idx,
                       float *samples, void *stream);
 
 /* The whole reverse chain, mixed_diffusion.py:425-454 (and gaussian_diffusion.py:133-152 when n_cat = 0):
@@ -179,15 +185,15 @@ int td_decode_samples(const td_diffusion_config *cfg, int32_t batch, const float
  *   noise_host_or_null / uniforms: optional externally supplied draws, (T+1, ...) in loop order with
  *   index 0 = prior, index 1 + s = step t = T-1-s; NULL = Philox.
  *   samples: (B, data_channels, L) fp32 on the device. */
-size_t td_sample_chain_workspace_bytes(const td_rnn_config *rnn, const td_diffusion_config *cfg, int32_t batch);
-int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_config *cfg, const void *packed,
+TD_API size_t td_sample_chain_workspace_bytes(const td_rnn_config *rnn, const td_diffusion_config *cfg, int32_t batch);
+TD_API int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_config *cfg, const void *packed,
                     const float *const *misc_host, const float *film_table, int32_t batch, const float *noise,
                     const float *uniforms, td_rng rng, int32_t use_graph, float *samples, void *workspace,
                     void *stream);
 
 /* Releases the cached step graph of td_sample_chain (waits for the stream it was launched on).
  * No counterpart in the reference. */
-int td_sample_chain_release(void);
+TD_API int td_sample_chain_release(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,239 @@
+"""GPU parity: the HIP path (through the C ABI of libtimediff_hip.so) against the CPU oracle and the
+golden vectors captured from the reference.  Run on the GPU box: pytest -m gpu.
+
+Stated tolerances (BASELINE.json north_star):
+  * elementwise diffusion math (q_sample, reverse update, loss): fp32, 1e-5 relative / absolute;
+  * denoiser: bf16 MFMA operands with fp32 accumulate/state.  Against the oracle's emulation of the same
+    roundings: 1e-2 absolute on O(1) outputs (transcendental and summation-order differences flip an
+    occasional bf16 rounding of h); against the reference's fp32 outputs: 4e-2 absolute;
+  * categorical samples: bit-exact wherever the Gumbel-perturbed top-2 margin exceeds 1e-3 (t <= 10)
+    / 1e-5 (otherwise) when fed the same logits.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+BF16_EMUL_ATOL = 1e-2
+BF16_REF_ATOL = 4e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cu(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def den_kernels(sd, dev):
+    from timediff_amd.ops import DenoiserKernels
+    return DenoiserKernels({k: cu(v, dev) for k, v in sd.items()})
+
+
+def diff_kernels(g, L, T, dev, tables=None, data_channels=None):
+    from timediff_amd.ops import DiffusionKernels
+    tables = tables or orc.schedule(T, "cosine")
+    n = len(g["num_idx"]) + len(g["cat_idx"])
+    return DiffusionKernels(list(g["num_idx"]), list(g["cat_idx"]), list(g["K"]), L, T,
+                            {k: torch.from_numpy(v) for k, v in tables.items()}, data_channels or n, dev)
+
+
+def test_library_loaded():
+    from timediff_amd import _lib
+    assert _lib.lib().td_version() >= 100
+
+
+@pytest.mark.parametrize("name", ["lstm_bi", "lstm_uni", "gru_bi", "gru_uni", "lstm_bi_h92"])
+def test_denoiser_forward(name, dev):
+    g = load_golden("rnn_" + name)
+    sd = sub(g, "sd.")
+    den = den_kernels(sd, dev)
+    t = cu(g["time"], dev)
+    film, temb = den.time_film(t, want_temb=True)
+    o32 = orc.Denoiser(sd)
+    temb_ref, film_ref = o32.time_embed(g["time"])
+    np.testing.assert_allclose(temb.cpu().numpy(), g["temb"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(film.cpu().numpy(), film_ref, rtol=1e-4, atol=3e-5)
+
+    y, hidden = den.forward(cu(g["x"], dev), t, want_hidden=True)
+    y, hidden = y.cpu().numpy(), hidden.cpu().numpy()
+    y16, h16 = orc.Denoiser(sd, bf16=True).forward(g["x"], g["time"], want_hidden=True)
+    assert np.abs(hidden - h16).max() < BF16_EMUL_ATOL, np.abs(hidden - h16).max()
+    assert np.abs(y - y16).max() < BF16_EMUL_ATOL, np.abs(y - y16).max()
+    assert np.abs(hidden - g["hidden"]).max() < BF16_REF_ATOL
+    assert np.abs(y - g["y"]).max() < BF16_REF_ATOL, np.abs(y - g["y"]).max()
+
+
+def test_denoiser_ragged_batches(dev):
+    """Batch sizes that do not fill a 32-sequence wave tile / a 128-sequence workgroup."""
+    g = load_golden("rnn_lstm_bi")
+    sd = sub(g, "sd.")
+    den = den_kernels(sd, dev)
+    o16 = orc.Denoiser(sd, bf16=True)
+    rng = np.random.default_rng(0)
+    for B in (1, 33, 130):
+        x = rng.standard_normal((B, 14, 24)).astype(np.float32)
+        t = rng.integers(0, 1000, B)
+        y = den.forward(cu(x, dev), cu(t, dev)).cpu().numpy()
+        assert np.abs(y - o16.forward(x, t)).max() < BF16_EMUL_ATOL
+
+
+@pytest.mark.parametrize("name", ["eicu_T50", "k3mix_T1000", "hirid_lin_T50"])
+def test_q_sample_and_loss(name, dev):
+    g = load_golden("mixed_loss_" + name)
+    L, H, N, T = [int(v) for v in g["cfg"]]
+    tables = {k: g["sd." + k] for k in orc._TABLE_MAP.values()}
+    dk = diff_kernels(g, L, T, dev, tables=tables)
+    t = cu(g["t"], dev)
+    x_in, x0_idx, xt_idx, noise_out = dk.q_sample(cu(g["data"], dev), t, cu(g["noise"], dev), cu(g["uniforms"], dev))
+    np.testing.assert_allclose(x_in.cpu().numpy(), g["x_in"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(noise_out.cpu().numpy(), g["noise"])
+    np.testing.assert_array_equal(x0_idx.cpu().numpy(), g["data"][:, g["cat_idx"], :].astype(np.uint8))
+
+    # loss + gradient at the reference's own model output
+    od = orc.Diffusion(len(g["num_idx"]), g["K"], L, T, tables=tables)
+    lam = float(g["loss_lambda"])
+    ref = od.mixed_loss(g["model_out"], g["noise"], x0_idx.cpu().numpy(), xt_idx.cpu().numpy(), g["t"], lam)
+    loss, grad = dk.mixed_loss(cu(g["model_out"], dev), noise_out, x0_idx, xt_idx, t, lam)
+    np.testing.assert_allclose(loss.item(), ref["loss"], rtol=2e-5)
+    gs = float(np.abs(ref["grad"]).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), ref["grad"], rtol=1e-4, atol=1e-5 * gs)
+    # and against the reference's value (slack = the reference's cumulative-logsumexp noise)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-3)
+    # scaled gradient (gradient accumulation)
+    _, grad2 = dk.mixed_loss(cu(g["model_out"], dev), noise_out, x0_idx, xt_idx, t, lam, scale=0.5)
+    np.testing.assert_allclose(grad2.cpu().numpy(), 0.5 * grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["eicu", "k3mix"])
+def test_reverse_steps(name, dev):
+    g = load_golden(f"reverse_steps_{name}_T1000")
+    dk = diff_kernels(g, 12, 1000, dev)
+    od = orc.Diffusion(len(g["num_idx"]), g["K"], 12, 1000)
+    for i in g["steps"]:
+        p = f"t{i}."
+        z, idx = cu(g[p + "z"], dev), cu(g[p + "idx"], dev)
+        dk.reverse_step_(cu(g[p + "model_out"], dev), z, idx, int(i), cu(g[p + "noise"], dev), cu(g[p + "uniforms"], dev))
+        np.testing.assert_allclose(z.cpu().numpy(), g[p + "z_new"], rtol=1e-5, atol=1e-5)
+        margin = od.gumbel_margin(g[p + "log_theta"], g[p + "uniforms"])
+        safe = margin > (1e-3 if i <= 10 else 1e-5)
+        assert np.array_equal(idx.cpu().numpy()[safe], g[p + "idx_new"][safe])
+        # and bit-exact against the oracle given identical inputs
+        _, idx_o = od.reverse_step(g[p + "model_out"], g[p + "z"], g[p + "idx"], int(i), g[p + "noise"], g[p + "uniforms"])
+        assert (idx.cpu().numpy() != idx_o).mean() < 2e-3
+
+
+@pytest.mark.parametrize("name", ["eicu_lstm_T8", "k3mix_gru_T6", "hirid_lstm_uni_T5"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sample_chain_external_noise(name, use_graph, dev):
+    from timediff_amd.ops import SamplerKernels
+    g = load_golden("sample_chain_" + name)
+    L, H, N, T, bidir, gru = [int(v) for v in g["cfg"]]
+    tables = {k: g["sd." + k] for k in orc._TABLE_MAP.values()}
+    sd = sub(g, "sd.model.")
+    c_io = len(g["num_idx"]) + int(g["K"].sum())
+    dk = diff_kernels(g, L, T, dev, tables=tables, data_channels=c_io - len(g["cat_idx"]))
+    sampler = SamplerKernels(den_kernels(sd, dev), dk)
+    noise = np.concatenate([g["z_T"][None], g["noise"]])
+    uniforms = np.concatenate([g["u_prior"][None], g["uniforms"]])
+    out = sampler.sample(g["z_T"].shape[0], cu(noise, dev), cu(uniforms, dev), use_graph=use_graph).cpu().numpy()
+    # oracle with the kernel's bf16 roundings, same draws
+    od = orc.Diffusion(len(g["num_idx"]), g["K"], L, T, tables=tables)
+    o16 = orc.Denoiser(sd, bf16=True)
+    z, idx = od.sample_chain(o16, g["z_T"], od.prior_categorical(g["u_prior"]), g["noise"], g["uniforms"])
+    want = od.decode(z, idx, g["num_idx"], g["cat_idx"], channels=c_io)
+    assert out.shape == g["sample"].shape
+    cat = list(g["cat_idx"])
+    mism = (out[:, cat] != want[:, cat]).mean()
+    assert mism < 0.03, mism
+    num = list(g["num_idx"])
+    assert np.abs(out[:, num] - want[:, num]).max() < 3e-2
+    # against the reference's fp32 chain: same statistics within the bf16 tolerance
+    assert (out[:, cat] != g["sample"][:, cat]).mean() < 0.06
+    assert np.abs(out[:, num] - g["sample"][:, num]).max() < 8e-2
+
+
+def test_gaussian_chain(dev):
+    from timediff_amd.ops import DiffusionKernels, SamplerKernels
+    g = load_golden("gaussian_T6")
+    C_, L, H, N, T = [int(v) for v in g["cfg"]]
+    tables = orc.schedule(T, "cosine")
+    dk = DiffusionKernels(list(range(C_)), [], [], L, T, {k: torch.from_numpy(v) for k, v in tables.items()}, C_, dev)
+    sd = sub(g, "sd.model.")
+    sampler = SamplerKernels(den_kernels(sd, dev), dk)
+    noise = np.concatenate([g["z_T"][None], g["chain_noise"]])
+    out = sampler.sample(g["z_T"].shape[0], cu(noise, dev), None).cpu().numpy()
+    assert np.abs(out - g["sample"]).max() < 8e-2
+    # loss of the Gaussian process (gaussian_diffusion.py:164-182)
+    x_in, _, _, noise_out = dk.q_sample(cu(g["data"], dev), cu(g["t"], dev), cu(g["noise"], dev), None)
+    mo = den_kernels(sd, dev).forward(x_in, cu(g["t"], dev))
+    e = torch.empty(g["data"].shape[0], 0, L, dtype=torch.uint8, device=dev)
+    loss, _ = dk.mixed_loss(mo, noise_out, e, e, cu(g["t"], dev), 0.0)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-2)
+
+
+def test_philox_streams_match_oracle(dev):
+    g = load_golden("reverse_steps_eicu_T1000")
+    dk = diff_kernels(g, 12, 1000, dev)
+    z, idx = dk.prior(5, seed=1234, patient0=7)
+    z = z.cpu().numpy()
+    for b in (0, 4):
+        for l in (0, 11):
+            want = orc.philox_normals(1234, 7 + b, l, 1000, 4)
+            np.testing.assert_allclose(z[b, :, l], want, rtol=1e-5, atol=1e-6)
+    # patient-keyed: a shard starting at patient 9 reproduces rows 2.. of the run above
+    z2, idx2 = dk.prior(3, seed=1234, patient0=9)
+    np.testing.assert_array_equal(z2.cpu().numpy(), z[2:5])
+    np.testing.assert_array_equal(idx2.cpu().numpy(), idx.cpu().numpy()[2:5])
+    od = orc.Diffusion(4, g["K"], 12, 1000)
+    u = np.stack([np.stack([orc.philox_uniforms(1234, 7 + b, l, 1000, 10) for l in range(12)], axis=1) for b in range(5)])
+    np.testing.assert_array_equal(idx.cpu().numpy(), od.prior_categorical(u))
+
+
+def test_eicu_shape_step_properties(dev):
+    """BASELINE config #2 shape (C_io 14, L 272, H 256, 3 layers, bidirectional) at a batch the oracle
+    finishes in seconds, plus size-independent properties on a larger batch."""
+    torch.manual_seed(0)
+    H, L, C = 256, 272, 14
+    sd = {}
+    k = 1.0 / np.sqrt(H)
+    for l in range(3):
+        for sfx in ("", "_reverse"):
+            In = C if l == 0 else 2 * H
+            sd[f"rnn.rnn.weight_ih_l{l}{sfx}"] = (torch.rand(4 * H, In) * 2 - 1) * k
+            sd[f"rnn.rnn.weight_hh_l{l}{sfx}"] = (torch.rand(4 * H, H) * 2 - 1) * k
+            sd[f"rnn.rnn.bias_ih_l{l}{sfx}"] = (torch.rand(4 * H) * 2 - 1) * k
+            sd[f"rnn.rnn.bias_hh_l{l}{sfx}"] = (torch.rand(4 * H) * 2 - 1) * k
+    sd["time_emb.1.weight"] = torch.randn(256, 64) / 8; sd["time_emb.1.bias"] = torch.zeros(256)
+    sd["time_emb.3.weight"] = torch.randn(256, 256) / 16; sd["time_emb.3.bias"] = torch.zeros(256)
+    sd["rnn.time_mlp.1.weight"] = torch.randn(4 * H, 256) / 16; sd["rnn.time_mlp.1.bias"] = torch.zeros(4 * H)
+    sd["rnn.norm.weight"] = torch.ones(2 * H); sd["rnn.norm.bias"] = torch.zeros(2 * H)
+    sd["fc.weight"] = torch.randn(C, 2 * H) / np.sqrt(2 * H); sd["fc.bias"] = torch.zeros(C)
+    sd = {k_: v.numpy() for k_, v in sd.items()}
+    den = den_kernels(sd, dev)
+    B = 4
+    x = torch.randn(B, C, L)
+    x[:, 4:] = torch.where(torch.rand(B, 10, L) > 0.5, 0.0, -69.07755279)
+    t = torch.tensor([999, 500, 3, 0])
+    y = den.forward(x.to(dev), t.to(dev)).cpu().numpy()
+    y16 = orc.Denoiser(sd, bf16=True).forward(x.numpy(), t.numpy())
+    assert np.abs(y - y16).max() < 2e-2, np.abs(y - y16).max()
+    # batch independence: sequences do not interact, whatever tile they land in
+    Bb = 300
+    xb = torch.randn(Bb, C, L)
+    xb[:4] = x
+    tb = torch.randint(0, 1000, (Bb,))
+    tb[:4] = t
+    yb = den.forward(xb.to(dev), tb.to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(yb[:4], y)
+    perm = torch.randperm(Bb)
+    yp = den.forward(xb[perm].to(dev), tb[perm].to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(yp, yb[perm.numpy()])

@@ -1,0 +1,95 @@
+"""ctypes binding of libtimediff_hip.so (include/timediff_hip.h).
+
+The library is built in-tree by `make -C timediff_amd/csrc` (or __graft_entry__.build()).  There is
+no CPU or eager-PyTorch fallback: if the shared object is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtimediff_hip.so")
+
+TD_MAX_CAT = 32
+TD_MISC_COUNT = 10
+TAB_ROWS = ["sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+            "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+            "posterior_log_variance_clipped", "log_alpha", "log_1_min_alpha", "log_cumprod_alpha",
+            "log_1_min_cumprod_alpha"]
+MISC_KEYS = ["time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_emb.3.bias",
+             "rnn.time_mlp.1.weight", "rnn.time_mlp.1.bias", "rnn.norm.weight", "rnn.norm.bias",
+             "fc.weight", "fc.bias"]
+
+
+class RnnConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("c_in", "hidden", "c_out", "layers", "dirs", "gru", "embed_dim", "time_dim")]
+
+
+class DiffusionConfig(C.Structure):
+    _fields_ = [("n_num", C.c_int32), ("n_cat", C.c_int32), ("seq_len", C.c_int32), ("timesteps", C.c_int32),
+                ("num_classes", C.c_int32 * TD_MAX_CAT), ("num_index", C.c_int32 * (2 * TD_MAX_CAT)),
+                ("cat_index", C.c_int32 * TD_MAX_CAT), ("data_channels", C.c_int32), ("tables", C.c_void_p)]
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("patient0", C.c_uint32), ("tag", C.c_uint32)]
+
+
+class TimediffError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = C.c_void_p
+_I = C.c_int32
+_SIGS = {
+    "td_version": (C.c_int, []),
+    "td_last_error": (C.c_char_p, []),
+    "td_rnn_packed_bytes": (C.c_size_t, [C.POINTER(RnnConfig)]),
+    "td_rnn_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
+    "td_rnn_pack_weights": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _P]),
+    "td_rnn_time_film": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _I, _P, _P, _P]),
+    "td_rnn_forward": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "td_rnn_read_hidden": (C.c_int, [C.POINTER(RnnConfig), _P, _I, _I, _P, _P]),
+    "td_q_sample_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, Rng, _P, _P, _P, _P, _P]),
+    "td_mixed_loss_workspace_bytes": (C.c_size_t, [C.POINTER(DiffusionConfig), _I]),
+    "td_mixed_loss": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "td_sample_prior": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, Rng, _P, _P, _P]),
+    "td_build_denoiser_input": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P]),
+    "td_reverse_step_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _I, _P, _P, _P, Rng, _P]),
+    "td_decode_samples": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P]),
+    "td_sample_chain_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), C.POINTER(DiffusionConfig), _I]),
+    "td_sample_chain": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(DiffusionConfig), _P, C.POINTER(_P), _P, _I, _P, _P,
+                                  Rng, _I, _P, _P, _P]),
+    "td_sample_chain_release": (C.c_int, []),
+}
+
+
+def lib():
+    """The loaded shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TimediffError(
+                f"{LIB_PATH} is missing: build it with `make -C timediff_amd/csrc` (there is no fallback path)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TimediffError(lib().td_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_table(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

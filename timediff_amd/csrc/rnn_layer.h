@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         char *dbase = lwave + buf * TD_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < TD_STAGE_FRAGS / TD_BLOCK_WAVES; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase + i * TD_FRAG_BYTES + lane16),
+            // keep each piece's base in SGPRs (saddr + 32-bit voffset form); without the laundering the
+            // compiler folds the piece offsets into per-lane 64-bit addresses and hoists all of them
+            const char *sp = sbase + i * TD_FRAG_BYTES;
+            asm volatile("" : "+s"(sp));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + lane16),
                                              (__attribute__((address_space(3))) void *)(dbase + i * TD_FRAG_BYTES), 16, 0, 0);
         }
     };
