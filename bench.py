@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthetic patient sequences / second through the FULL T = 1000 reverse chain.
+
+Workload (BASELINE.json configs[1]): eICU-shaped ETDiff -- 4 continuous + 5 binary channels
+(C_io = 14), L = 272, 3-layer bidirectional LSTM denoiser with H = 256, random-init weights
+(seed 2023), bf16 MFMA denoiser with fp32 state, in-kernel Philox noise.  One "step" = one complete
+chain (prior draw -> T x (denoiser + reverse update) -> decode) for `--batch` sequences per GPU, replayed
+as a captured hipGraph.  Patients are sharded across ranks (disjoint Philox patient ids), no data-path
+collective: weak scaling.
+
+    python bench.py --gpus 1 --steps 1 --warmup 0
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+EICU = dict(num=[0, 2, 4, 6], cat=[1, 3, 5, 7, 8], K=[2, 2, 2, 2, 2])
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def init_state(C_io, H, N, D, seed):
+    """Random-init weights of the architecture with torch's default nn.LSTM / nn.Linear initialisers."""
+    g = torch.Generator().manual_seed(seed)
+
+    def u(shape, k):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * k
+
+    sd = {}
+    k = 1.0 / np.sqrt(H)
+    for l in range(N):
+        for d in range(D):
+            sfx = f"_l{l}" + ("_reverse" if d else "")
+            In = C_io if l == 0 else D * H
+            sd[f"rnn.rnn.weight_ih{sfx}"] = u((4 * H, In), k)
+            sd[f"rnn.rnn.weight_hh{sfx}"] = u((4 * H, H), k)
+            sd[f"rnn.rnn.bias_ih{sfx}"] = u((4 * H,), k)
+            sd[f"rnn.rnn.bias_hh{sfx}"] = u((4 * H,), k)
+    sd["time_emb.1.weight"] = u((256, 64), 1 / 8.0); sd["time_emb.1.bias"] = u((256,), 1 / 8.0)
+    sd["time_emb.3.weight"] = u((256, 256), 1 / 16.0); sd["time_emb.3.bias"] = u((256,), 1 / 16.0)
+    sd["rnn.time_mlp.1.weight"] = u((2 * D * H, 256), 1 / 16.0); sd["rnn.time_mlp.1.bias"] = u((2 * D * H,), 1 / 16.0)
+    sd["rnn.norm.weight"] = torch.ones(D * H); sd["rnn.norm.bias"] = torch.zeros(D * H)
+    kf = 1.0 / np.sqrt(D * H)
+    sd["fc.weight"] = u((C_io, D * H), kf); sd["fc.bias"] = u((C_io,), kf)
+    return sd
+
+
+def denoiser_flops_per_seq(C_io, H, N, D, L):
+    """BASELINE.md section 4 / SURVEY.md 8(d): algorithmic FLOPs of one denoiser forward for one sequence."""
+    f = 0.0
+    for l in range(N):
+        In = C_io if l == 0 else D * H
+        f += D * 2.0 * L * 4 * H * (In + H)
+    f += 2.0 * L * D * H * C_io + 2.0 * (64 * 256 + 256 * 256 + 256 * 2 * D * H)
+    return f
+
+
+def cpu_baseline(sd, cols, L, T, tables, seconds_target=15.0):
+    """The oracle (CPU restatement, fp32, OpenMP over sequences) timed on this box's host cores on a bounded
+    sample of the same workload: a few reverse steps of a small batch, extrapolated to the T-step chain."""
+    from oracle import oracle as orc
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    den = orc.Denoiser({k: v.numpy() for k, v in sd.items()})
+    od = orc.Diffusion(len(cols["num"]), cols["K"], L, T, tables=tables)
+    B = 2 * threads
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((B, len(cols["num"]), L)).astype(np.float32)
+    idx = rng.integers(0, 2, (B, len(cols["K"]), L)).astype(np.uint8)
+    steps, t0 = 0, time.time()
+    while True:
+        t = np.full((B,), T - 1 - steps, np.int64)
+        mo = den.forward(od.build_x_in(z, idx), t)
+        z, idx = od.reverse_step(mo, z, idx, t, rng.standard_normal(z.shape).astype(np.float32),
+                                 rng.random((B, sum(cols["K"]), L), dtype=np.float32))
+        steps += 1
+        el = time.time() - t0
+        if el > seconds_target or steps >= 50:
+            break
+    per_step = el / steps
+    return dict(value=B / (per_step * T), unit="sequences/s", cores=threads, kind="port",
+                sample=f"{steps} reverse steps (denoiser + update) of {B} eICU-shaped sequences, fp32 oracle, "
+                       f"{per_step:.2f} s/step, extrapolated to T={T}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=16384, help="sequences per GPU per chain")
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--seq-len", type=int, default=272)
+    ap.add_argument("--probe-steps", type=int, default=8, help="eager reverse steps timed with HIP events for the roofline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from timediff_amd import _lib
+    from timediff_amd.ops import DenoiserKernels, DiffusionKernels, SamplerKernels
+    from timediff_amd.schedule import make_tables
+
+    cols, L, T, H, N, D = EICU, args.seq_len, args.timesteps, args.hidden, 3, 2
+    C_io = len(cols["num"]) + sum(cols["K"])
+    sd = init_state(C_io, H, N, D, seed=2023)
+    tables = make_tables(T, "cosine")
+    den = DenoiserKernels({k: v.to(dev) for k, v in sd.items()})
+    diff = DiffusionKernels(cols["num"], cols["cat"], cols["K"], L, T, tables, len(cols["num"]) + len(cols["cat"]), dev)
+    sampler = SamplerKernels(den, diff)
+    sampler.refresh()
+    B = args.batch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def chain(i):
+        # every chain draws fresh patients: ids are disjoint across ranks and chains
+        return sampler.sample(B, seed=2023, patient0=(i * world + rank) * B)
+
+    # untimed: one short pass through every kernel so allocations and code objects are in place
+    pre = SamplerKernels(den, DiffusionKernels(cols["num"], cols["cat"], cols["K"], L, 4, make_tables(4, "cosine"),
+                                               len(cols["num"]) + len(cols["cat"]), dev))
+    pre.sample(B, seed=1)
+    for w in range(args.warmup):
+        chain(-1 - w)
+    barrier()
+    t0 = time.time()
+    for i in range(args.steps):
+        out = chain(i)
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+    value = world * B * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # roofline probe of the dominant kernel (recurrent layers above the first: td_rnn_layer_kernel<8,32,0,0>):
+        # eager reverse steps with a HIP event pair around each launch on its own stream
+        L_ = _lib.lib()
+        z, idx = diff.prior(B, seed=7)
+        _lib.check(L_.td_profile_enable(1))
+        for s in range(args.probe_steps):
+            t = T - 1 - s
+            mo = den.forward(diff.build_input(z, idx), film=sampler._film[t:t + 1])
+            diff.reverse_step_(mo, z, idx, t, seed=7)
+        cnt, ms = C.c_int32(0), C.c_float(0)
+        _lib.check(L_.td_profile_read(C.byref(cnt), C.byref(ms)))
+        _lib.check(L_.td_profile_enable(0))
+        avg_s = ms.value / max(cnt.value, 1) * 1e-3
+        flops_launch = B * D * 2.0 * L * 4 * H * (D * H + H)       # one launch = one layer, both directions
+        achieved = flops_launch / avg_s / 1e12
+        roofline = dict(bound="mfma", kernel="td_rnn_layer_kernel<NU=8,KX=32,L0=0,GRU=0>", achieved=achieved,
+                        peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK_TFLOPS,
+                        traffic=None, launches_timed=cnt.value, avg_launch_ms=avg_s * 1e3,
+                        flops_per_launch=flops_launch)
+        base = None
+        if not args.no_cpu_baseline:
+            base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()})
+        fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
+        result = {
+            "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,
+            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ETDiff eICU-shaped sampler: C_io=14 (4 continuous + 5 binary), L=272, "
+                                   f"3-layer bidirectional LSTM H={H}, T={T}, random-init weights, Philox noise",
+                       "batch_per_gpu": B, "sequences_per_step": world * B, "parallelism": f"patient-sharded x{world}",
+                       "graph": True},
+            "denoiser_tflops_whole_chain": value * fl / 1e12,
+            "roofline": roofline, "cpu_baseline": base,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

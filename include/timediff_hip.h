@@ -195,6 +195,13 @@ TD_API int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_config *
  * No counterpart in the reference. */
 TD_API int td_sample_chain_release(void);
 
+/* Measurement aid, no counterpart in the reference: while enabled, every recurrent-layer kernel of the
+ * widest kind (layers above the first) launched outside graph capture is bracketed by HIP events on
+ * its own stream; td_profile_read waits for them and returns how many launches were timed and the sum
+ * of their durations (ms), then resets. */
+TD_API int td_profile_enable(int32_t on);
+TD_API int td_profile_read(int32_t *count, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

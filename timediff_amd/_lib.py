@@ -62,6 +62,8 @@ _SIGS = {
     "td_sample_chain": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(DiffusionConfig), _P, C.POINTER(_P), _P, _I, _P, _P,
                                   Rng, _I, _P, _P, _P]),
     "td_sample_chain_release": (C.c_int, []),
+    "td_profile_enable": (C.c_int, [_I]),
+    "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
 }
 
 
@@ -72,6 +74,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TimediffError(
                 f"{LIB_PATH} is missing: build it with `make -C timediff_amd/csrc` (there is no fallback path)")
+        # torch's wheel carries its own libamdhip64: it has to be in the process first, so that the
+        # library binds to the same HIP runtime that owns the tensors' memory and streams
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)

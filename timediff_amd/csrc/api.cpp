@@ -15,3 +15,60 @@ void td_set_error(const char *fmt, ...) {
 
 extern "C" const char *td_last_error(void) { return g_err; }
 extern "C" int td_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline probe).
+// Not used inside graph capture.  No counterpart in the reference.
+// ---------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+
+#define TD_PROF_MAX 1024
+static struct {
+    int on, count;
+    hipEvent_t start[TD_PROF_MAX], stop[TD_PROF_MAX];
+    int created;
+} g_prof;
+
+extern "C" int td_profile_enable(int on) {
+    if (on && !g_prof.created) {
+        for (int i = 0; i < TD_PROF_MAX; ++i) {
+            if (hipEventCreate(&g_prof.start[i]) != hipSuccess || hipEventCreate(&g_prof.stop[i]) != hipSuccess) {
+                td_set_error("hipEventCreate failed");
+                return TD_ERR_HIP;
+            }
+        }
+        g_prof.created = 1;
+    }
+    g_prof.on = on;
+    g_prof.count = 0;
+    return TD_OK;
+}
+
+// called by the recurrent-layer launcher: returns the slot to stop, or -1
+int td_profile_begin(void *stream) {
+    if (!g_prof.on || g_prof.count >= TD_PROF_MAX) return -1;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
+    int slot = g_prof.count++;
+    (void)hipEventRecord(g_prof.start[slot], (hipStream_t)stream);
+    return slot;
+}
+void td_profile_end(int slot, void *stream) {
+    if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], (hipStream_t)stream);
+}
+
+extern "C" int td_profile_read(int32_t *count, float *total_ms) {
+    float total = 0.f;
+    for (int i = 0; i < g_prof.count; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]) != hipSuccess) {
+            td_set_error("reading profile event %d failed", i);
+            return TD_ERR_HIP;
+        }
+        total += ms;
+    }
+    if (count) *count = g_prof.count;
+    if (total_ms) *total_ms = total;
+    g_prof.count = 0;
+    return TD_OK;
+}

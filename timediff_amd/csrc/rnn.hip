@@ -391,6 +391,9 @@ static int td_launch_layer_any(int nu, const TdLayerParams &p, bool layer0, int 
     return TD_ERR_UNSUPPORTED;
 }
 
+int td_profile_begin(void *stream);
+void td_profile_end(int slot, void *stream);
+
 // Runs pack-input + all recurrent layers; returns the buffer holding the last layer's fragments.
 int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, void *workspace,
                       hipStream_t stream, const char **last_act) {
@@ -418,8 +421,10 @@ int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float 
         p.xin = in; p.out = out;
         p.in_frags = lg.xfr; p.out_frags = g.dirs * g.kh;
         p.L = L; p.nbb = nbb; p.dirs = g.dirs;
+        const int slot = l > 0 ? td_profile_begin(stream) : -1;
         rc = cfg->gru ? td_launch_layer_any<true>(g.nu, p, l == 0, l == 0 ? g.kx0 : g.dirs, stream)
                       : td_launch_layer_any<false>(g.nu, p, l == 0, l == 0 ? g.kx0 : g.dirs, stream);
+        td_profile_end(slot, stream);
         if (rc != TD_OK) return rc;
         in = out;
         out = out == actA ? actB : actA;
