@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtimediff_hip.so")
+LIB_PATH = os.environ.get("TIMEDIFF_HIP_LIB") or os.path.join(_HERE, "libtimediff_hip.so")
 
 TD_MAX_CAT = 32
 TD_MISC_COUNT = 10

@@ -24,6 +24,20 @@ __device__ __forceinline__ void td_static_for(F &&f) {
     }
 }
 
+// The recurrent state (128 fp32 registers per lane at H = 256) is only touched once per time step,
+// so it is parked in the accumulator half of the register file between uses: the VALU-addressable
+// half stays free for the operand prefetch rings.
+__device__ __forceinline__ float td_park(float v) {
+    float a;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    return a;
+}
+__device__ __forceinline__ float td_unpark(float a) {
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
 struct TdLayerParams {
     const char *wpacked;  // packed weights of this layer, direction 0
     size_t dir_stride;    // bytes to direction 1
@@ -45,6 +59,7 @@ struct TdLayerTraits {
     static constexpr int LDS_H = TD_BLOCK_WAVES * KH * TD_FRAG_BYTES;
     static constexpr int LDS_TOTAL = LDS_W + LDS_H;
     static constexpr int XPD = L0 ? XFR : (KX < 8 ? KX : 8);  // input fragments in flight per wave
+    static constexpr int APD = 8;                              // weight fragments read ahead of their MFMA
 };
 
 template <int NU, int KX, bool L0, bool GRU>
@@ -75,8 +90,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
     const unsigned lane16 = lane * 16;
     const char *wwave = wp + (size_t)wave * (TD_STAGE_FRAGS / TD_BLOCK_WAVES) * TD_FRAG_BYTES;
     char *lwave = lds + wave * (TD_STAGE_FRAGS / TD_BLOCK_WAVES) * TD_FRAG_BYTES;
-    auto issue_stage = [&](int stage, int buf) {
-        const char *sbase = wwave + (size_t)stage * TD_STAGE_BYTES;
+    auto issue_stage = [&](const char *wsrc, int stage, int buf) {
+        const char *sbase = wsrc + (size_t)stage * TD_STAGE_BYTES;
         char *dbase = lwave + buf * TD_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < TD_STAGE_FRAGS / TD_BLOCK_WAVES; ++i) {
@@ -89,13 +104,13 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         }
     };
 
-    f32x16 state[NU];  // LSTM: cell state c; GRU: hidden state h in fp32
+    float state[NU][16];  // LSTM: cell state c; GRU: hidden state h in fp32 (parked, see td_park)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) state[u][r] = 0.f;
+        for (int r = 0; r < 16; ++r) state[u][r] = td_park(0.f);
 
-    issue_stage(0, 0);
+    issue_stage(wwave, 0, 0);
     int bufsel = 1;  // toggled at every stage boundary; the first boundary selects buffer 0
 
     // B operand of the bias k-step: ones at k = 0, 1 (the bias rides in as bf16 hi + lo columns)
@@ -116,8 +131,14 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         const bool last_step = s + 1 == p.L;
         char *op = p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES + lane * 16;
 
+        // the per-step base pointer is laundered so that nothing derived from it is loop-invariant:
+        // otherwise every stage's DMA base gets hoisted out of the time loop and spilled
+        const char *wstep = wwave;
+        asm volatile("" : "+s"(wstep));
+
         td_static_for<NU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
+            constexpr int base = u * FU;
             if constexpr (!L0) {
 #pragma unroll
                 for (int i = 0; i < T::XPD; ++i) xf[i] = xp[i * 64];
@@ -130,72 +151,87 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 
             // fetch weight fragment f of this step's stream (compile-time f after unrolling)
             auto wfrag = [&](int f) -> bf16x8 {
+#ifdef TD_ABLATE_DMA
+                if (false) {
+#else
                 if (f % TD_STAGE_FRAGS == 0) {
+#endif
                     const int stage = f / TD_STAGE_FRAGS;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of `stage` have landed
                     __syncthreads();                                   // everyone's have; stage-1 is fully consumed
                     bufsel ^= 1;
-                    if (stage + 1 < NS) issue_stage(stage + 1, bufsel ^ 1);
-                    else if (!last_step) issue_stage(0, bufsel ^ 1);
+                    if (stage + 1 < NS) issue_stage(wstep, stage + 1, bufsel ^ 1);
+                    else if (!last_step) issue_stage(wstep, 0, bufsel ^ 1);
                 }
                 return *(const bf16x8 *)(lds + bufsel * TD_STAGE_BYTES + (f % TD_STAGE_FRAGS) * TD_FRAG_BYTES + lane * 16);
             };
+            auto hfrag = [&](int ks) -> bf16x8 { return *(const bf16x8 *)(hreg + ks * TD_FRAG_BYTES + lane * 16); };
 
-            // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag(u * FU + g), ones, acc[g], 0, 0, 0);
-            // recurrent part: h_{t-1} fragments from this wave's LDS region
-#pragma unroll
-            for (int ks = 0; ks < KH; ++ks) {
-                const bf16x8 b = *(const bf16x8 *)(hreg + ks * TD_FRAG_BYTES + lane * 16);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const bf16x8 a = wfrag(u * FU + 4 + ks * NG + g);
-                    const int ai = (GRU && g == 2) ? 3 : g;
-                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ai], 0, 0, 0);
-                }
-            }
-            // input part
-            if constexpr (L0) {
-#pragma unroll
-                for (int kx = 0; kx < KX; ++kx)
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const int f = u * FU + 4 + KH * NG + (kx * NG + g) * 2;
-                        const bf16x8 whi = wfrag(f);
-                        const bf16x8 wlo = wfrag(f + 1);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xf[2 * kx], acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xf[2 * kx + 1], acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xf[2 * kx], acc[g], 0, 0, 0);
+            // Weight fragments are read APD ahead of the MFMA that consumes them (LDS latency is ~100+ cycles,
+            // an MFMA 32): the ring A[] is statically indexed, so it lives in registers.
+            constexpr int APD = T::APD;
+            bf16x8 A[APD];
+            td_static_for<APD>([&](auto ic) { A[decltype(ic)::value] = wfrag(base + decltype(ic)::value); });
+            bf16x8 hb[2];
+            hb[0] = hfrag(0);
+
+            td_static_for<FU>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                const bf16x8 a = A[f % APD];
+                if constexpr (f + APD < FU) A[f % APD] = wfrag(base + f + APD);
+                // pin the read-ahead: left alone, the scheduler sinks every ds_read next to its MFMA and the
+                // wave then pays the full LDS latency per MFMA
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (f < 4) {
+                    // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[f], 0, 0, 0);
+                } else if constexpr (f - 4 < KH * NG) {
+                    // recurrent part: h_{t-1} fragments from this wave's LDS region, one k-step ahead
+                    constexpr int ks = (f - 4) / NG, g = (f - 4) % NG;
+                    if constexpr (g == 0 && ks + 1 < KH) hb[(ks + 1) % 2] = hfrag(ks + 1);
+                    constexpr int ai = (GRU && g == 2) ? 3 : g;
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[ks % 2], acc[ai], 0, 0, 0);
+                } else if constexpr (L0) {
+                    // first layer: W = Whi + Wlo, x = xhi + xlo in bf16; keep the three leading products
+                    constexpr int x = f - 4 - KH * NG;
+                    constexpr int part = x & 1, kx = (x >> 1) / NG, g = (x >> 1) % NG;
+                    if constexpr (part == 0) {
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[2 * kx + 1], acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[2 * kx], acc[g], 0, 0, 0);
+                    } else {
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[2 * kx], acc[g], 0, 0, 0);
                     }
-            } else {
-#pragma unroll
-                for (int kx = 0; kx < KX; ++kx) {
-                    const bf16x8 b = xf[kx % T::XPD];
-                    if (kx + T::XPD < KX) xf[kx % T::XPD] = xp[(kx + T::XPD) * 64];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const bf16x8 a = wfrag(u * FU + 4 + (KH + kx) * NG + g);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
-                    }
+                } else {
+                    constexpr int x = f - 4 - KH * NG;
+                    constexpr int kx = x / NG, g = x % NG;
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[kx % T::XPD], acc[g], 0, 0, 0);
+                    if constexpr (g == NG - 1 && kx + T::XPD < KX) xf[kx % T::XPD] = xp[(kx + T::XPD) * 64];
                 }
-            }
+            });
 
             // gate nonlinearities; row r of the accumulator = unit 32u + (r&3) + 8(r>>2) + 4hf
             float hv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#ifdef TD_ABLATE_POINTWISE
+                {
+                    const float cv = 0.5f * td_unpark(state[u][r]) + 0.01f * (acc[0][r] + acc[1][r] + acc[2][r] + acc[3][r]);
+                    state[u][r] = td_park(cv);
+                    hv[r] = 0.5f * cv;
+                    continue;
+                }
+#endif
                 if constexpr (!GRU) {
                     const float ig = td_sigmoid(acc[0][r]), fg = td_sigmoid(acc[1][r]);
                     const float gg = td_tanh(acc[2][r]), og = td_sigmoid(acc[3][r]);
-                    const float cv = fg * state[u][r] + ig * gg;
-                    state[u][r] = cv;
+                    const float cv = fg * td_unpark(state[u][r]) + ig * gg;
+                    state[u][r] = td_park(cv);
                     hv[r] = og * td_tanh(cv);
                 } else {
                     const float rg = td_sigmoid(acc[0][r]), zg = td_sigmoid(acc[1][r]);
                     const float ng = td_tanh(acc[2][r] + rg * acc[3][r]);
-                    const float h = (1.0f - zg) * ng + zg * state[u][r];
-                    state[u][r] = h;
+                    const float h = (1.0f - zg) * ng + zg * td_unpark(state[u][r]);
+                    state[u][r] = td_park(h);
                     hv[r] = h;
                 }
             }
