@@ -97,6 +97,25 @@ TD_API int td_rnn_forward(const td_rnn_config *cfg, const void *packed, const fl
 TD_API int td_rnn_read_hidden(const td_rnn_config *cfg, const void *workspace, int32_t batch, int32_t seq_len, float *hidden,
                        void *stream);
 
+/* Training (accelerator.backward(loss), et_diff.py:237, through blocks.py:333-341).
+ * td_rnn_forward_train = td_rnn_forward with one film row per batch element, keeping in `workspace`
+ * (td_rnn_train_workspace_bytes) every layer's output, the gate activations and bf16 row-major copies of
+ * the activations.  td_rnn_backward consumes that workspace:
+ *   grad_y (B, c_out, L) -> grad_layer_host[...] (same indexing as layer_weights_host, fp32 torch layout,
+ *   ACCUMULATED into), grad_misc_host[TD_LN_W, TD_LN_B, TD_FC_W, TD_FC_B] (accumulated; other slots
+ *   ignored), grad_film (B, 2*D*H) (overwritten; the time-embedding MLP's backward is the caller's).
+ * packT: transposed bf16 weight fragments (td_rnn_packT_bytes / td_rnn_pack_weights_T), a derived cache
+ * like `packed`.  Gradients are computed from bf16-rounded activations and gate gradients with fp32
+ * accumulation; float atomics make the last bits run-dependent. */
+TD_API size_t td_rnn_train_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
+TD_API size_t td_rnn_packT_bytes(const td_rnn_config *cfg);
+TD_API int td_rnn_pack_weights_T(const td_rnn_config *cfg, const float *const *layer_weights_host, void *packT, void *stream);
+TD_API int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed, const float *const *misc_host, const float *x,
+                         const float *film, int32_t batch, int32_t seq_len, float *y, void *workspace, void *stream);
+TD_API int td_rnn_backward(const td_rnn_config *cfg, const void *packT, const float *const *misc_host, const float *film,
+                    const float *grad_y, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer_host,
+                    float *const *grad_misc_host, float *grad_film, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Mixed diffusion: models/ETDiff/mixed_diffusion.py MixedDiffusion (:68-454); n_cat = 0 gives
  * models/ETDiff/gaussian_diffusion.py GaussianDiffusion.

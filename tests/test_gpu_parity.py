@@ -237,3 +237,32 @@ def test_eicu_shape_step_properties(dev):
     perm = torch.randperm(Bb)
     yp = den.forward(xb[perm].to(dev), tb[perm].to(dev)).cpu().numpy()
     np.testing.assert_array_equal(yp, yb[perm.numpy()])
+
+
+# ---------------------------------------------------------------------------------------------
+# training path
+# ---------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("name", ["lstm_bi", "lstm_uni", "gru_bi", "gru_uni", "lstm_bi_h92"])
+def test_denoiser_backward(name, dev):
+    """d loss / d parameters through the HIP backward against the reference's autograd (golden) and the
+    fp32 oracle.  bf16 operands in forward and backward: 3 % of each tensor's largest entry."""
+    from timediff_amd import _lib
+    g = load_golden("rnn_" + name)
+    sd = sub(g, "sd.")
+    den = den_kernels(sd, dev)
+    t = cu(g["time"], dev)
+    film = den.time_film(t)
+    y = den.forward_train(cu(g["x"], dev), film)
+    y16 = orc.Denoiser(sd, bf16=True).forward(g["x"], g["time"])
+    assert np.abs(y.cpu().numpy() - y16).max() < BF16_EMUL_ATOL
+    g_layer, g_misc, g_film = den.backward(cu(g["grad_y"], dev), film)
+    for key, got in list(zip(den._lkeys, g_layer)) + list(g_misc.items()):
+        ref = g["grad." + key]
+        assert _rel(got.cpu().numpy(), ref) < 3e-2, (key, _rel(got.cpu().numpy(), ref))
+    # d film against the oracle's chain: grad of time_mlp.1.bias is the batch sum of d film
+    np.testing.assert_allclose(g_film.sum(0).cpu().numpy(), g["grad.rnn.time_mlp.1.bias"], rtol=3e-2,
+                               atol=3e-2 * np.abs(g["grad.rnn.time_mlp.1.bias"]).max())

@@ -51,6 +51,12 @@ _SIGS = {
     "td_rnn_time_film": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _I, _P, _P, _P]),
     "td_rnn_forward": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "td_rnn_read_hidden": (C.c_int, [C.POINTER(RnnConfig), _P, _I, _I, _P, _P]),
+    "td_rnn_train_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
+    "td_rnn_packT_bytes": (C.c_size_t, [C.POINTER(RnnConfig)]),
+    "td_rnn_pack_weights_T": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _P]),
+    "td_rnn_forward_train": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, _P, _P]),
+    "td_rnn_backward": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, C.POINTER(_P),
+                                  C.POINTER(_P), _P, _P]),
     "td_q_sample_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, Rng, _P, _P, _P, _P, _P]),
     "td_mixed_loss_workspace_bytes": (C.c_size_t, [C.POINTER(DiffusionConfig), _I]),
     "td_mixed_loss": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),

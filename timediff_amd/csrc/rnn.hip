@@ -1,48 +1,9 @@
 // Denoiser forward: weight packing, time embedding + FiLM, layer-0 input packing, the recurrent
 // layers (rnn_layer.h) and the LayerNorm + FiLM + fc head.  Reference: models/ETDiff/blocks.py.
-#include "rnn_layer.h"
+#include "rnn_launch.h"
+#include "rnn_geom.h"
 
 #include <math.h>
-
-// ---------------------------------------------------------------------------------------------
-// geometry shared by all entry points
-// ---------------------------------------------------------------------------------------------
-struct TdRnnGeom {
-    int nu, hpad, kh, kx0, dirs, layers;
-    TdLayerGeom g0, g1;  // layer 0 / layers above
-    size_t layer_off[16];
-    size_t packed_bytes;
-};
-
-static int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
-    TD_REQUIRE(cfg != nullptr, "td_rnn_config is NULL");
-    TD_REQUIRE(cfg->dirs == 1 || cfg->dirs == 2, "dirs must be 1 or 2, got %d", cfg->dirs);
-    TD_REQUIRE(cfg->layers >= 1 && cfg->layers <= 16, "layers must be in [1,16], got %d", cfg->layers);
-    TD_REQUIRE(cfg->hidden >= 1 && cfg->c_in >= 1 && cfg->c_out >= 1, "non-positive channel count");
-    TD_REQUIRE(cfg->c_out <= 32, "c_out = %d > 32 is not supported", cfg->c_out);
-    TD_REQUIRE(cfg->embed_dim >= 4 && cfg->embed_dim % 2 == 0 && cfg->embed_dim <= 1024, "bad embed_dim %d", cfg->embed_dim);
-    TD_REQUIRE(cfg->time_dim >= 1 && cfg->time_dim <= 1024, "bad time_dim %d", cfg->time_dim);
-    int nu = td_round_nu(cfg->hidden);
-    if (nu < 0) {
-        td_set_error("hidden = %d > 256 is not supported by this build", cfg->hidden);
-        return TD_ERR_UNSUPPORTED;
-    }
-    int kx0 = (cfg->c_in + 15) / 16;
-    if (kx0 > 2) {
-        td_set_error("c_in = %d > 32 is not supported by this build", cfg->c_in);
-        return TD_ERR_UNSUPPORTED;
-    }
-    g->nu = nu; g->hpad = 32 * nu; g->kh = 2 * nu; g->kx0 = kx0; g->dirs = cfg->dirs; g->layers = cfg->layers;
-    g->g0 = td_layer_geom(nu, cfg->gru, 1, kx0);
-    g->g1 = td_layer_geom(nu, cfg->gru, 0, cfg->dirs);
-    size_t off = 0;
-    for (int l = 0; l < cfg->layers; ++l) {
-        g->layer_off[l] = off;
-        off += (l == 0 ? g->g0.dir_bytes : g->g1.dir_bytes) * cfg->dirs;
-    }
-    g->packed_bytes = off;
-    return TD_OK;
-}
 
 extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
     TdRnnGeom g;
@@ -357,53 +318,25 @@ __global__ void td_unpack_hidden_kernel(const char *act, float *hidden, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// layer dispatch
+// layer dispatch (templates in rnn_launch.h; the SAVE = true instantiations live in rnn_train.hip)
 // ---------------------------------------------------------------------------------------------
-template <int NU, int KX, bool L0, bool GRU>
-static int td_launch_layer(const TdLayerParams &p, hipStream_t stream) {
-    const int tiles = td_cdiv(p.nbb, TD_BLOCK_WAVES);
-    hipLaunchKernelGGL((td_rnn_layer_kernel<NU, KX, L0, GRU>), dim3(tiles * p.dirs), dim3(256), 0, stream, p);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+int td_launch_layer_infer(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
+    return gru ? td_launch_layer_any<true, false>(nu, p, layer0, kxsel, stream)
+               : td_launch_layer_any<false, false>(nu, p, layer0, kxsel, stream);
 }
-
-template <int NU, bool GRU>
-static int td_launch_layer_nu(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    if (layer0) {
-        if (kxsel == 1) return td_launch_layer<NU, 1, true, GRU>(p, stream);
-        return td_launch_layer<NU, 2, true, GRU>(p, stream);
-    }
-    if (kxsel == 1) return td_launch_layer<NU, 2 * NU, false, GRU>(p, stream);
-    return td_launch_layer<NU, 4 * NU, false, GRU>(p, stream);
-}
-
-template <bool GRU>
-static int td_launch_layer_any(int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    switch (nu) {
-        case 1: return td_launch_layer_nu<1, GRU>(p, layer0, kxsel, stream);
-        case 2: return td_launch_layer_nu<2, GRU>(p, layer0, kxsel, stream);
-        case 3: return td_launch_layer_nu<3, GRU>(p, layer0, kxsel, stream);
-        case 4: return td_launch_layer_nu<4, GRU>(p, layer0, kxsel, stream);
-        case 6: return td_launch_layer_nu<6, GRU>(p, layer0, kxsel, stream);
-        case 8: return td_launch_layer_nu<8, GRU>(p, layer0, kxsel, stream);
-    }
-    td_set_error("unsupported hidden block count %d", nu);
-    return TD_ERR_UNSUPPORTED;
-}
+int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
 
 int td_profile_begin(void *stream);
 void td_profile_end(int slot, void *stream);
 
-// Runs pack-input + all recurrent layers; returns the buffer holding the last layer's fragments.
-int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, void *workspace,
-                      hipStream_t stream, const char **last_act) {
+// Runs pack-input + all recurrent layers.  acts[l] receives layer l's output fragments; saves[l] (training)
+// the per-step gate activations.  Inference ping-pongs two activation buffers.
+int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
+                         char *const *acts, float *const *saves, hipStream_t stream) {
     TdRnnGeom g;
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
-    size_t x0_bytes, act_bytes;
-    td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
     const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
-    char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
     {
         size_t total = (size_t)L * nbb * g.kx0 * 64;
         int blocks = (int)((total + 255) / 256);
@@ -412,25 +345,42 @@ int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float 
         TD_LAUNCH_CHECK();
     }
     const char *in = x0;
-    char *out = actA;
     for (int l = 0; l < cfg->layers; ++l) {
         const TdLayerGeom &lg = l == 0 ? g.g0 : g.g1;
         TdLayerParams p;
         p.wpacked = (const char *)packed + g.layer_off[l];
         p.dir_stride = lg.dir_bytes;
-        p.xin = in; p.out = out;
+        p.xin = in; p.out = acts[l];
         p.in_frags = lg.xfr; p.out_frags = g.dirs * g.kh;
         p.L = L; p.nbb = nbb; p.dirs = g.dirs;
-        const int slot = l > 0 ? td_profile_begin(stream) : -1;
-        rc = cfg->gru ? td_launch_layer_any<true>(g.nu, p, l == 0, l == 0 ? g.kx0 : g.dirs, stream)
-                      : td_launch_layer_any<false>(g.nu, p, l == 0, l == 0 ? g.kx0 : g.dirs, stream);
-        td_profile_end(slot, stream);
+        p.save = saves ? saves[l] : nullptr;
+        p.save_dir_stride = (size_t)L * nbb * g.nu * 5 * 1024;
+        const int kxsel = l == 0 ? g.kx0 : g.dirs;
+        if (saves) {
+            rc = td_launch_layer_save(cfg->gru, g.nu, p, l == 0, kxsel, stream);
+        } else {
+            const int slot = l > 0 ? td_profile_begin(stream) : -1;
+            rc = td_launch_layer_infer(cfg->gru, g.nu, p, l == 0, kxsel, stream);
+            td_profile_end(slot, stream);
+        }
         if (rc != TD_OK) return rc;
-        in = out;
-        out = out == actA ? actB : actA;
+        in = acts[l];
     }
-    *last_act = in;
     return TD_OK;
+}
+
+int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, void *workspace,
+                      hipStream_t stream, const char **last_act) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    size_t x0_bytes, act_bytes;
+    td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
+    char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
+    char *acts[16];
+    for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
+    *last_act = acts[cfg->layers - 1];
+    return td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, stream);
 }
 
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,

@@ -1,0 +1,45 @@
+// Derived geometry of a denoiser configuration (shared by rnn.hip and rnn_train.hip).
+#pragma once
+#include "common.h"
+#include "rnn_layout.h"
+
+// ---------------------------------------------------------------------------------------------
+// geometry shared by all entry points
+// ---------------------------------------------------------------------------------------------
+struct TdRnnGeom {
+    int nu, hpad, kh, kx0, dirs, layers;
+    TdLayerGeom g0, g1;  // layer 0 / layers above
+    size_t layer_off[16];
+    size_t packed_bytes;
+};
+
+static inline int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
+    TD_REQUIRE(cfg != nullptr, "td_rnn_config is NULL");
+    TD_REQUIRE(cfg->dirs == 1 || cfg->dirs == 2, "dirs must be 1 or 2, got %d", cfg->dirs);
+    TD_REQUIRE(cfg->layers >= 1 && cfg->layers <= 16, "layers must be in [1,16], got %d", cfg->layers);
+    TD_REQUIRE(cfg->hidden >= 1 && cfg->c_in >= 1 && cfg->c_out >= 1, "non-positive channel count");
+    TD_REQUIRE(cfg->c_out <= 32, "c_out = %d > 32 is not supported", cfg->c_out);
+    TD_REQUIRE(cfg->embed_dim >= 4 && cfg->embed_dim % 2 == 0 && cfg->embed_dim <= 1024, "bad embed_dim %d", cfg->embed_dim);
+    TD_REQUIRE(cfg->time_dim >= 1 && cfg->time_dim <= 1024, "bad time_dim %d", cfg->time_dim);
+    int nu = td_round_nu(cfg->hidden);
+    if (nu < 0) {
+        td_set_error("hidden = %d > 256 is not supported by this build", cfg->hidden);
+        return TD_ERR_UNSUPPORTED;
+    }
+    int kx0 = (cfg->c_in + 15) / 16;
+    if (kx0 > 2) {
+        td_set_error("c_in = %d > 32 is not supported by this build", cfg->c_in);
+        return TD_ERR_UNSUPPORTED;
+    }
+    g->nu = nu; g->hpad = 32 * nu; g->kh = 2 * nu; g->kx0 = kx0; g->dirs = cfg->dirs; g->layers = cfg->layers;
+    g->g0 = td_layer_geom(nu, cfg->gru, 1, kx0);
+    g->g1 = td_layer_geom(nu, cfg->gru, 0, cfg->dirs);
+    size_t off = 0;
+    for (int l = 0; l < cfg->layers; ++l) {
+        g->layer_off[l] = off;
+        off += (l == 0 ? g->g0.dir_bytes : g->g1.dir_bytes) * cfg->dirs;
+    }
+    g->packed_bytes = off;
+    return TD_OK;
+}
+

@@ -45,6 +45,10 @@ struct TdLayerParams {
     char *out;            // output fragments [l][bblk][out_frags][64][8] bf16
     int in_frags, out_frags;
     int L, nbb, dirs;
+    // training only (SAVE kernels): gate activations and state for the backward pass,
+    // [dir][l][bblk][u][5][64 lanes][16] fp32 in accumulator layout: LSTM i,f,g,o,c ; GRU r,z,n,(W_hn h + b_hn),h
+    float *save;
+    size_t save_dir_stride;  // floats
 };
 
 template <int NU, int KX, bool L0, bool GRU>
@@ -62,7 +66,7 @@ struct TdLayerTraits {
     static constexpr int APD = 8;                              // weight fragments read ahead of their MFMA
 };
 
-template <int NU, int KX, bool L0, bool GRU>
+template <int NU, int KX, bool L0, bool GRU, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
     using T = TdLayerTraits<NU, KX, L0, GRU>;
     constexpr int NG = T::NG, KH = T::KH, XFR = T::XFR, FU = T::FU, NS = T::NS;
@@ -211,6 +215,9 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 
             // gate nonlinearities; row r of the accumulator = unit 32u + (r&3) + 8(r>>2) + 4hf
             float hv[16];
+            float *svp = nullptr;
+            if constexpr (SAVE)
+                svp = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bb) * NU + u) * 5) * 1024 + lane * 16;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
 #ifdef TD_ABLATE_POINTWISE
@@ -227,12 +234,22 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     const float cv = fg * td_unpark(state[u][r]) + ig * gg;
                     state[u][r] = td_park(cv);
                     hv[r] = og * td_tanh(cv);
+                    if constexpr (SAVE) {
+                        if (active) {
+                            svp[r] = ig; svp[1024 + r] = fg; svp[2048 + r] = gg; svp[3072 + r] = og; svp[4096 + r] = cv;
+                        }
+                    }
                 } else {
                     const float rg = td_sigmoid(acc[0][r]), zg = td_sigmoid(acc[1][r]);
                     const float ng = td_tanh(acc[2][r] + rg * acc[3][r]);
                     const float h = (1.0f - zg) * ng + zg * td_unpark(state[u][r]);
                     state[u][r] = td_park(h);
                     hv[r] = h;
+                    if constexpr (SAVE) {
+                        if (active) {
+                            svp[r] = rg; svp[1024 + r] = zg; svp[2048 + r] = ng; svp[3072 + r] = acc[3][r]; svp[4096 + r] = h;
+                        }
+                    }
                 }
             }
 #pragma unroll

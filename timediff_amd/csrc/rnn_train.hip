@@ -1,0 +1,684 @@
+// Denoiser training path: forward that keeps what the backward pass needs, and the backward pass
+// (autograd of models/ETDiff/blocks.py:333-341 as run by accelerator.backward, et_diff.py:237).
+//
+// Backward decomposition (first version: correct and parallel at the reference's small training
+// batches; the sweep is a launch per time step, not yet a persistent kernel):
+//   head_bwd      d y -> d h_top (bf16 fragments), d film, d LayerNorm, d fc           (one pass, LDS atomics)
+//   per layer, top down:
+//     bptt_point  per step: gate-gradient arithmetic, d a_t as MFMA fragments + plain rows
+//     frag_gemm   per step: d h_{t-1} = W_hh^T d a_t          (MFMA, accumulator -> operand trick)
+//     frag_gemm   all steps at once: d x = W_ih^T d a         (gradient for the layer below)
+//     dw_gemm     d W = d a . [x ; h_prev]^T over all (sequence, step) columns   (MFMA, split-K, fp32 atomics)
+//     bias_reduce d b = row sums of d a
+#include "rnn_geom.h"
+#include "rnn_launch.h"
+
+int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
+    return gru ? td_launch_layer_any<true, true>(nu, p, layer0, kxsel, stream)
+               : td_launch_layer_any<false, true>(nu, p, layer0, kxsel, stream);
+}
+
+int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
+                         char *const *acts, float *const *saves, hipStream_t stream);
+int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
+                const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------------------------------------
+// training workspace
+// ---------------------------------------------------------------------------------------------
+struct TdTrainLayout {
+    int nbb, Bp, cpad;      // batch blocks, padded batch, layer-0 channels padded to 32
+    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dhrec[2], dc[2], total;
+    size_t act_bytes, save_dir_floats, daf_bytes, dapl_slab_elems, cols;
+};
+
+static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &g, int batch, int L) {
+    TdTrainLayout t;
+    t.nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    t.Bp = t.nbb * 32;
+    t.cpad = 32 * td_cdiv(cfg->c_in, 32);
+    t.cols = (size_t)L * t.Bp;
+    t.act_bytes = (size_t)L * t.nbb * (g.dirs * g.kh) * TD_FRAG_BYTES;
+    t.save_dir_floats = (size_t)L * t.nbb * g.nu * 5 * 1024;
+    t.daf_bytes = (size_t)L * t.nbb * 4 * g.kh * TD_FRAG_BYTES;
+    t.dapl_slab_elems = (size_t)g.hpad * t.cols;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    t.x0 = take((size_t)L * t.nbb * g.g0.xfr * TD_FRAG_BYTES);
+    for (int l = 0; l < cfg->layers; ++l) t.act[l] = take(t.act_bytes);
+    for (int l = 0; l < cfg->layers; ++l) t.save[l] = take(t.save_dir_floats * g.dirs * sizeof(float));
+    t.plain[0] = take((size_t)t.cpad * t.cols * 2);
+    for (int l = 1; l <= cfg->layers; ++l) t.plain[l] = take((size_t)g.dirs * g.hpad * t.cols * 2);
+    for (int l = 0; l < cfg->layers; ++l)
+        for (int s = 0; s < 2; ++s) t.gout[l][s] = take(t.act_bytes);
+    for (int l = 0; l < cfg->layers; ++l)
+        for (int d = 0; d < g.dirs; ++d) {
+            t.daf[l][d] = take(t.daf_bytes);
+            t.dapl[l][d] = take(4 * t.dapl_slab_elems * 2);
+        }
+    for (int d = 0; d < 2; ++d) {
+        t.dhrec[d] = take((size_t)t.nbb * g.kh * TD_FRAG_BYTES);
+        t.dc[d] = take((size_t)t.nbb * g.nu * 1024 * sizeof(float));
+    }
+    t.total = off;
+    return t;
+}
+
+extern "C" size_t td_rnn_train_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len) {
+    TdRnnGeom g;
+    if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0 || seq_len <= 0) return 0;
+    return td_train_layout(cfg, g, batch, seq_len).total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plain (row-major, column = l*Bp + b) bf16 copies of the activations: operands of the dW GEMM
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void td_x_to_plain_kernel(const float *__restrict__ x, __bf16 *__restrict__ out, int B, int C,
+                                                            int cpad, int L, int Bp) {
+    const size_t total = (size_t)cpad * L * Bp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i % Bp), l = (int)((i / Bp) % L), c = (int)(i / ((size_t)Bp * L));
+        float v = 0.f;
+        if (b < B && c < C) v = x[((size_t)b * C + c) * L + l];
+        out[i] = (__bf16)v;
+    }
+}
+
+// act fragments [l][bblk][D*KH][64][8] -> rows (d*hpad + unit), columns l*Bp + b
+__global__ __launch_bounds__(256) void td_frags_to_plain_kernel(const __bf16 *__restrict__ act, __bf16 *__restrict__ out, int L,
+                                                                int nbb, int kh, int dirs) {
+    const int Bp = nbb * 32, hpad = kh * 16;
+    const size_t total = (size_t)dirs * hpad * L * Bp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i % Bp), l = (int)((i / Bp) % L);
+        const int row = (int)(i / ((size_t)Bp * L));
+        const int d = row / hpad, unit = row % hpad;
+        const int ks = unit / 16, w = unit % 16, hf = (w >> 2) & 1, j = ((w >> 3) << 2) | (w & 3);
+        const size_t frag = ((size_t)l * nbb + b / 32) * (dirs * kh) + d * kh + ks;
+        out[i] = act[frag * 512 + (hf * 32 + (b % 32)) * 8 + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward with saves
+// ---------------------------------------------------------------------------------------------
+extern "C" int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,
+                                    const float *film, int32_t batch, int32_t seq_len, float *y, void *workspace,
+                                    void *stream_) {
+    TD_REQUIRE(cfg && packed && misc && x && film && y && workspace, "NULL argument");
+    TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const TdTrainLayout t = td_train_layout(cfg, g, batch, seq_len);
+    char *ws = (char *)workspace;
+    char *acts[16];
+    float *saves[16];
+    for (int l = 0; l < cfg->layers; ++l) {
+        acts[l] = ws + t.act[l];
+        saves[l] = (float *)(ws + t.save[l]);
+    }
+    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, stream);
+    if (rc != TD_OK) return rc;
+    rc = td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, batch, nullptr, batch, seq_len, y, stream);
+    if (rc != TD_OK) return rc;
+    // plain copies for the weight-gradient GEMMs
+    hipLaunchKernelGGL(td_x_to_plain_kernel, dim3(2048), dim3(256), 0, stream, x, (__bf16 *)(ws + t.plain[0]), batch, cfg->c_in,
+                       t.cpad, seq_len, t.Bp);
+    TD_LAUNCH_CHECK();
+    for (int l = 0; l < cfg->layers; ++l) {
+        hipLaunchKernelGGL(td_frags_to_plain_kernel, dim3(4096), dim3(256), 0, stream, (const __bf16 *)acts[l],
+                           (__bf16 *)(ws + t.plain[l + 1]), seq_len, t.nbb, g.kh, g.dirs);
+        TD_LAUNCH_CHECK();
+    }
+    return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transposed weight packing for the backward fragment GEMMs
+//   WT[rb][term][ks][lane (r, hf)][j] = W[gate(term)*H + unit(ks, hf, j)][col(32 rb + r)]
+// k (the contraction index) runs over gate units in the order the d a fragments hold them.
+// ---------------------------------------------------------------------------------------------
+struct TdPackTParams {
+    const float *w;
+    __bf16 *dst;
+    int H, ld, kh, nterm, nrb, nu, hh;  // hh: columns are this layer's own hidden units; else [dir][unit] of the layer below
+    int gate[4];
+};
+
+__global__ __launch_bounds__(256) void td_pack_weights_T_kernel(TdPackTParams p) {
+    const size_t total = (size_t)p.nrb * p.nterm * p.kh * 512;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i % 8), lane = (int)((i / 8) % 64);
+        const int ks = (int)((i / 512) % p.kh), term = (int)((i / (512 * (size_t)p.kh)) % p.nterm);
+        const int rb = (int)(i / (512 * (size_t)p.kh * p.nterm));
+        const int r = lane & 31, hf = lane >> 5;
+        const int unit = 16 * ks + 8 * (j >> 2) + 4 * hf + (j & 3);
+        int col = -1;
+        if (p.hh) {
+            if (32 * rb + r < p.H) col = 32 * rb + r;
+        } else {
+            const int dsrc = rb / p.nu, us = 32 * (rb % p.nu) + r;
+            if (us < p.H) col = dsrc * p.H + us;
+        }
+        float v = 0.f;
+        if (unit < p.H && col >= 0) v = p.w[(size_t)(p.gate[term] * p.H + unit) * p.ld + col];
+        p.dst[i] = (__bf16)v;
+    }
+}
+
+struct TdPackTGeom {
+    size_t hh_bytes, ih_bytes, dir_bytes, layer_off[16], total;
+    int ng;
+};
+
+static TdPackTGeom td_packT_geom(const td_rnn_config *cfg, const TdRnnGeom &g) {
+    TdPackTGeom t;
+    t.ng = cfg->gru ? 3 : 4;
+    t.hh_bytes = (size_t)g.nu * t.ng * g.kh * TD_FRAG_BYTES;
+    t.ih_bytes = (size_t)(g.dirs * g.nu) * t.ng * g.kh * TD_FRAG_BYTES;  // layers above the first only
+    size_t off = 0;
+    for (int l = 0; l < cfg->layers; ++l) {
+        t.layer_off[l] = off;
+        off += (t.hh_bytes + (l > 0 ? t.ih_bytes : 0)) * g.dirs;
+    }
+    t.total = off;
+    return t;
+}
+
+extern "C" size_t td_rnn_packT_bytes(const td_rnn_config *cfg) {
+    TdRnnGeom g;
+    if (td_rnn_geom(cfg, &g) != TD_OK) return 0;
+    return td_packT_geom(cfg, g).total;
+}
+
+extern "C" int td_rnn_pack_weights_T(const td_rnn_config *cfg, const float *const *lw, void *packT, void *stream) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    TD_REQUIRE(lw && packT, "NULL argument");
+    const TdPackTGeom t = td_packT_geom(cfg, g);
+    for (int l = 0; l < cfg->layers; ++l)
+        for (int d = 0; d < cfg->dirs; ++d) {
+            const float *const *w = lw + (size_t)(l * cfg->dirs + d) * 4;
+            char *base = (char *)packT + t.layer_off[l] + (size_t)d * (t.hh_bytes + (l > 0 ? t.ih_bytes : 0));
+            TdPackTParams p;
+            p.H = cfg->hidden; p.kh = g.kh; p.nterm = t.ng; p.nu = g.nu;
+            for (int i = 0; i < 4; ++i) p.gate[i] = i;
+            // W_hh^T: rows of the result = own hidden units
+            p.w = w[1]; p.ld = cfg->hidden; p.dst = (__bf16 *)base; p.nrb = g.nu; p.hh = 1;
+            hipLaunchKernelGGL(td_pack_weights_T_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+            TD_LAUNCH_CHECK();
+            if (l > 0) {
+                p.w = w[0]; p.ld = cfg->dirs * cfg->hidden; p.dst = (__bf16 *)(base + t.hh_bytes); p.nrb = g.dirs * g.nu; p.hh = 0;
+                hipLaunchKernelGGL(td_pack_weights_T_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, p);
+                TD_LAUNCH_CHECK();
+            }
+        }
+    return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// head backward
+// ---------------------------------------------------------------------------------------------
+struct TdHeadBwdParams {
+    const char *act;
+    const float *ln_w, *ln_b, *fc_w, *film, *gy;
+    char *gout;                                   // d h_top fragments (same layout as act)
+    float *d_film, *d_ln_w, *d_ln_b, *d_fc_w, *d_fc_b;  // accumulated (atomics)
+    int B, L, nbb, H, hpad, kh, dirs, c_out;
+};
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float hl[];
+    const int DHP = p.dirs * p.hpad, DH = p.dirs * p.H;
+    float *s_lnw = hl, *s_lnb = hl + DHP, *s_fcw = hl + 2 * DHP;
+    float *a_lnw = s_fcw + CMAX * DHP, *a_lnb = a_lnw + DHP, *a_fcw = a_lnb + DHP, *a_fcb = a_fcw + CMAX * DHP;
+    for (int i = threadIdx.x; i < DHP; i += 256) {
+        const int d = i / p.hpad, unit = i % p.hpad;
+        const bool ok = unit < p.H;
+        s_lnw[i] = ok ? p.ln_w[d * p.H + unit] : 0.f;
+        s_lnb[i] = ok ? p.ln_b[d * p.H + unit] : 0.f;
+        a_lnw[i] = 0.f; a_lnb[i] = 0.f;
+        for (int c = 0; c < CMAX; ++c) {
+            s_fcw[c * DHP + i] = (ok && c < p.c_out) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
+            a_fcw[c * DHP + i] = 0.f;
+        }
+    }
+    if (threadIdx.x < CMAX) a_fcb[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
+    const int KT = p.dirs * p.kh;
+    const size_t ntask = (size_t)p.L * p.nbb;
+    for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
+        const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
+        const int b = bblk * 32 + m;
+        const bool valid = b < p.B;
+        const bf16x8 *fp = (const bf16x8 *)(p.act + task * KT * TD_FRAG_BYTES) + lane;
+        float sum = 0.f;
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)v[j];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum / (float)DH;
+        float sq = 0.f;
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+            const int unit0 = 16 * (ks % p.kh) + 4 * hf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = (float)v[j] - mu;
+                sq += (unit0 + 8 * (j >> 2) + (j & 3)) < p.H ? dlt * dlt : 0.f;
+            }
+        }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
+        float g[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) g[c] = (valid && c < p.c_out) ? p.gy[((size_t)b * p.c_out + c) * p.L + l] : 0.f;
+        const float *film = p.film + (size_t)(valid ? b : 0) * 2 * DH;
+        float *dfilm = p.d_film + (size_t)(valid ? b : 0) * 2 * DH;
+
+        // pass A: parameter gradients and the two LayerNorm-backward means
+        float m1 = 0.f, m2 = 0.f;
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+            const int d = ks / p.kh;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+                if (unit >= p.H) continue;
+                const int ip = d * p.hpad + unit, feat = d * p.H + unit;
+                const float xh = ((float)v[j] - mu) * rstd;
+                const float lnout = xh * s_lnw[ip] + s_lnb[ip];
+                const float sc1 = film[feat] + 1.0f;
+                const float yf = lnout * sc1 + film[DH + feat];
+                float dyf = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    dyf += g[c] * s_fcw[c * DHP + ip];
+                    if (c < p.c_out && valid) atomicAdd(&a_fcw[c * DHP + ip], g[c] * yf);
+                }
+                if (valid) {
+                    atomicAdd(&dfilm[feat], dyf * lnout);
+                    atomicAdd(&dfilm[DH + feat], dyf);
+                    const float dln = dyf * sc1;
+                    atomicAdd(&a_lnw[ip], dln * xh);
+                    atomicAdd(&a_lnb[ip], dln);
+                    const float dxh = dln * s_lnw[ip];
+                    m1 += dxh;
+                    m2 += dxh * xh;
+                }
+            }
+        }
+        if (hf == 0 && valid) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < p.c_out) atomicAdd(&a_fcb[c], g[c]);
+        }
+        m1 += __shfl_xor(m1, 32);
+        m2 += __shfl_xor(m2, 32);
+        m1 /= (float)DH;
+        m2 /= (float)DH;
+        // pass B: d h
+        bf16x8 *op = (bf16x8 *)(p.gout + task * KT * TD_FRAG_BYTES) + lane;
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+            const int d = ks / p.kh;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+                float dh = 0.f;
+                if (unit < p.H && valid) {
+                    const int ip = d * p.hpad + unit, feat = d * p.H + unit;
+                    const float xh = ((float)v[j] - mu) * rstd;
+                    float dyf = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) dyf += g[c] * s_fcw[c * DHP + ip];
+                    const float dxh = dyf * (film[feat] + 1.0f) * s_lnw[ip];
+                    dh = rstd * (dxh - m1 - xh * m2);
+                }
+                o[j] = (__bf16)dh;
+            }
+            op[ks * 64] = o;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DHP; i += 256) {
+        const int d = i / p.hpad, unit = i % p.hpad;
+        if (unit >= p.H) continue;
+        const int feat = d * p.H + unit;
+        atomicAdd(&p.d_ln_w[feat], a_lnw[i]);
+        atomicAdd(&p.d_ln_b[feat], a_lnb[i]);
+        for (int c = 0; c < p.c_out; ++c) atomicAdd(&p.d_fc_w[(size_t)c * DH + feat], a_fcw[c * DHP + i]);
+    }
+    if ((int)threadIdx.x < p.c_out) atomicAdd(&p.d_fc_b[threadIdx.x], a_fcb[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BPTT step, elementwise part: one wave per (direction, batch block, unit block)
+// ---------------------------------------------------------------------------------------------
+struct TdBpttParams {
+    const char *gsrc[2];     // gradient w.r.t. this layer's output (fragments), n_src of them are summed
+    int n_src;
+    const char *dhrec;       // [dir][bblk][KH] fragments: W_hh^T d a of the step processed before (or unused)
+    float *dc;               // [dir][bblk][NU][64][16]  LSTM: d c carried ; GRU: z * d h carried
+    const float *save;       // [dir][l][bblk][NU][5][64][16]
+    char *daf;               // [dir][l][bblk][4][KH] fragments
+    __bf16 *dapl;            // [dir][4][hpad][L*Bp]
+    size_t dhrec_dir, dc_dir, save_dir, daf_dir, dapl_dir;   // direction strides (bytes / floats / bytes / bytes / elems)
+    int s, L, nbb, nu, kh, dirs, out_frags, gru;
+};
+
+__global__ __launch_bounds__(64) void td_bptt_point_kernel(TdBpttParams p) {
+    const int u = blockIdx.x, bblk = blockIdx.y, d = blockIdx.z, lane = threadIdx.x;
+    const int hf = lane >> 5, m = lane & 31;
+    // BPTT visits this direction's steps in reverse processing order
+    const int pos = p.L - 1 - p.s;                 // position in the direction's forward order
+    const int l = d ? p.L - 1 - pos : pos;
+    const int lprev = d ? l + 1 : l - 1;           // the step processed before l in the forward pass
+    const bool has_prev = pos > 0, first = p.s == 0;
+    float dh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+    for (int sidx = 0; sidx < p.n_src; ++sidx) {
+        const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+        const bf16x8 a = gp[0], b = gp[64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dh[j] += (float)a[j]; dh[8 + j] += (float)b[j]; }
+    }
+    float *dcp = p.dc + (size_t)d * p.dc_dir + (((size_t)bblk * p.nu + u) * 64 + lane) * 16;
+    float carry[16];
+    if (!first) {
+        const bf16x8 *rp = (const bf16x8 *)(p.dhrec + (size_t)d * p.dhrec_dir + ((size_t)bblk * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+        const bf16x8 a = rp[0], b = rp[64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dh[j] += (float)a[j]; dh[8 + j] += (float)b[j]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) carry[r] = dcp[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+    }
+    const float *sv = p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16;
+    const float *svp = p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16;
+    float da[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float prev = has_prev ? svp[r] : 0.f;   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+        if (!p.gru) {
+            const float ig = sv[r], fg = sv[1024 + r], gg = sv[2048 + r], og = sv[3072 + r], cv = sv[4096 + r];
+            const float tc = td_tanh(cv);
+            const float dcv = carry[r] + dh[r] * og * (1.0f - tc * tc);
+            da[0][r] = dcv * gg * ig * (1.0f - ig);
+            da[1][r] = dcv * prev * fg * (1.0f - fg);
+            da[2][r] = dcv * ig * (1.0f - gg * gg);
+            da[3][r] = dh[r] * tc * og * (1.0f - og);
+            carry[r] = dcv * fg;
+        } else {
+            const float rg = sv[r], zg = sv[1024 + r], ng = sv[2048 + r], hn = sv[3072 + r];
+            const float dht = dh[r] + carry[r];
+            const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
+            da[0][r] = dan * hn * rg * (1.0f - rg);
+            da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
+            da[2][r] = dan;
+            da[3][r] = dan * rg;
+            carry[r] = dht * zg;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dcp[r] = carry[r];
+    const size_t cols = (size_t)p.L * p.nbb * 32;
+    const int hpad = p.kh * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)da[g][j]; b[j] = (__bf16)da[g][8 + j]; }
+        bf16x8 *fp = (bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + g) * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+        fp[0] = a;
+        fp[64] = b;
+        __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)g * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int unit = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            pl[(size_t)unit * cols] = r < 8 ? a[r] : b[r - 8];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fragment GEMM: out[tile][2 rb + {0,1}] = sum_{term, ks} WT[rb][term][ks] x in[tile][slab(term) * KH + ks]
+// ---------------------------------------------------------------------------------------------
+struct TdFragGemmParams {
+    const char *wt;          // [rb][nterm][kh] fragments
+    const char *in;          // [tile][in_frags] fragments
+    char *out;               // [tile][out_frags] fragments; row block rb lands at frag out_off + 2 rb
+    size_t in_tile_off;      // fragments to skip at the start (selects one time step of a [l][bblk] array)
+    int in_frags, out_frags, out_off, ntiles, nrb, nterm, kh;
+    int slab[4];
+};
+
+__global__ __launch_bounds__(256) void td_frag_gemm_kernel(TdFragGemmParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rb = blockIdx.x * 4 + wave, tile = blockIdx.y;
+    if (rb >= p.nrb) return;
+    const bf16x8 *wp = (const bf16x8 *)(p.wt + (size_t)rb * p.nterm * p.kh * TD_FRAG_BYTES) + lane;
+    const bf16x8 *ip = (const bf16x8 *)(p.in + (p.in_tile_off + (size_t)tile * p.in_frags) * TD_FRAG_BYTES) + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int term = 0; term < p.nterm; ++term) {
+        const bf16x8 *bp = ip + (size_t)p.slab[term] * p.kh * 64;
+        const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
+#pragma unroll 4
+        for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
+    }
+    bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)acc[j]; b[j] = (__bf16)acc[8 + j]; }
+    bf16x8 *op = (bf16x8 *)(p.out + ((size_t)tile * p.out_frags + p.out_off + 2 * rb) * TD_FRAG_BYTES) + lane;
+    op[0] = a;
+    op[64] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-gradient GEMM: C[m][col(n)] += sum_k A[m][k] B[n][k]   (bf16 operands, fp32 atomics, split K)
+// ---------------------------------------------------------------------------------------------
+struct TdDwParams {
+    const __bf16 *A, *B;     // row-major, k contiguous
+    float *C;
+    size_t lda, ldb;
+    int ldc, M, N, K;        // M valid rows of A (rows beyond are zero-padded to a multiple of 32), N rows of B (multiple of 32)
+    int hp, hv;              // column map: n -> (n / hp) * hv + n % hp, valid when n % hp < hv
+    int kchunk;
+};
+
+__global__ __launch_bounds__(256) void td_dw_gemm_kernel(TdDwParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hf = lane >> 5;
+    const int mt = blockIdx.x, nt = blockIdx.y;
+    const int chunk = blockIdx.z * 4 + wave;
+    const int k0 = chunk * p.kchunk;
+    if (k0 >= p.K) return;
+    const int k1 = min(p.K, k0 + p.kchunk);
+    const __bf16 *ap = p.A + (size_t)(mt * 32 + r) * p.lda + 8 * hf;
+    const __bf16 *bp = p.B + (size_t)(nt * 32 + r) * p.ldb + 8 * hf;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int k = k0; k < k1; k += 16)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(ap + k), *(const bf16x8 *)(bp + k), acc, 0, 0, 0);
+    const int n = nt * 32 + r;   // accumulator column
+    if (n % p.hp < p.hv) {
+        const int col = (n / p.hp) * p.hv + n % p.hp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            if (m < p.M) atomicAdd(&p.C[(size_t)m * p.ldc + col], acc[i]);
+        }
+    }
+}
+
+// d b[m] += sum_k A[m][k] (one wave per row), added to up to two destinations
+__global__ __launch_bounds__(256) void td_bias_reduce_kernel(const __bf16 *A, size_t lda, int M, size_t K, float *dst0, float *dst1) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const __bf16 *row = A + (size_t)m * lda;
+    float s = 0.f;
+    for (size_t k = (size_t)lane * 8; k < K; k += 512) {
+        const bf16x8 v = *(const bf16x8 *)(row + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        if (dst0) atomicAdd(&dst0[m], s);
+        if (dst1) atomicAdd(&dst1[m], s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward entry point
+// ---------------------------------------------------------------------------------------------
+extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                               const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
+                               float *const *grad_layer, float *const *grad_misc, float *grad_film, void *stream_) {
+    TD_REQUIRE(cfg && packT && misc && film && grad_y && workspace && grad_layer && grad_misc && grad_film, "NULL argument");
+    TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int L = seq_len, N = cfg->layers, D = g.dirs, H = cfg->hidden, G = cfg->gru ? 3 : 4;
+    const TdTrainLayout t = td_train_layout(cfg, g, batch, L);
+    const TdPackTGeom tg = td_packT_geom(cfg, g);
+    char *ws = (char *)workspace;
+    const int DH = D * H;
+
+    // ---- head --------------------------------------------------------------------------------
+    TD_HIP(hipMemsetAsync(grad_film, 0, (size_t)batch * 2 * DH * sizeof(float), stream));
+    {
+        TdHeadBwdParams p;
+        p.act = ws + t.act[N - 1];
+        p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.film = film; p.gy = grad_y;
+        p.gout = ws + t.gout[N - 1][0];
+        p.d_film = grad_film; p.d_ln_w = grad_misc[TD_LN_W]; p.d_ln_b = grad_misc[TD_LN_B];
+        p.d_fc_w = grad_misc[TD_FC_W]; p.d_fc_b = grad_misc[TD_FC_B];
+        TD_REQUIRE(p.d_ln_w && p.d_ln_b && p.d_fc_w && p.d_fc_b, "NULL gradient pointer for the head parameters");
+        p.B = batch; p.L = L; p.nbb = t.nbb; p.H = H; p.hpad = g.hpad; p.kh = g.kh; p.dirs = D; p.c_out = cfg->c_out;
+        const size_t ntask = (size_t)L * t.nbb;
+        int blocks = (int)((ntask + 3) / 4);
+        if (blocks > 1024) blocks = 1024;
+        const int DHP = D * g.hpad;
+        if (cfg->c_out <= 16) {
+            const size_t shm = ((size_t)(4 + 2 * 16) * DHP + 16) * sizeof(float);
+            TD_HIP(hipFuncSetAttribute((const void *)td_head_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(td_head_bwd_kernel<16>, dim3(blocks), dim3(256), shm, stream, p);
+        } else {
+            const size_t shm = ((size_t)(4 + 2 * 32) * DHP + 32) * sizeof(float);
+            TD_HIP(hipFuncSetAttribute((const void *)td_head_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(td_head_bwd_kernel<32>, dim3(blocks), dim3(256), shm, stream, p);
+        }
+        TD_LAUNCH_CHECK();
+    }
+
+    // ---- layers, top down ------------------------------------------------------------------------
+    const int KT = D * g.kh;
+    for (int l = N - 1; l >= 0; --l) {
+        const int n_src = l == N - 1 ? 1 : D;
+        const size_t packT_dir = tg.hh_bytes + (l > 0 ? tg.ih_bytes : 0);
+        const char *wT = (const char *)packT + tg.layer_off[l];
+        for (int s = 0; s < L; ++s) {
+            TdBpttParams p;
+            p.gsrc[0] = ws + t.gout[l][0]; p.gsrc[1] = ws + t.gout[l][1]; p.n_src = n_src;
+            p.dhrec = ws + t.dhrec[0]; p.dhrec_dir = t.dhrec[1] - t.dhrec[0];
+            p.dc = (float *)(ws + t.dc[0]); p.dc_dir = (t.dc[1] - t.dc[0]) / sizeof(float);
+            p.save = (const float *)(ws + t.save[l]); p.save_dir = t.save_dir_floats;
+            p.daf = ws + t.daf[l][0]; p.daf_dir = D > 1 ? t.daf[l][1] - t.daf[l][0] : 0;
+            p.dapl = (__bf16 *)(ws + t.dapl[l][0]); p.dapl_dir = D > 1 ? (t.dapl[l][1] - t.dapl[l][0]) / 2 : 0;
+            p.s = s; p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
+            hipLaunchKernelGGL(td_bptt_point_kernel, dim3(g.nu, t.nbb, D), dim3(64), 0, stream, p);
+            TD_LAUNCH_CHECK();
+            if (s + 1 < L) {
+                for (int d = 0; d < D; ++d) {
+                    const int pos = L - 1 - s, lt = d ? L - 1 - pos : pos;
+                    TdFragGemmParams q;
+                    q.wt = wT + (size_t)d * packT_dir;
+                    q.in = ws + t.daf[l][d];
+                    q.in_tile_off = (size_t)lt * t.nbb * 4 * g.kh;
+                    q.in_frags = 4 * g.kh;
+                    q.out = ws + t.dhrec[d]; q.out_frags = g.kh; q.out_off = 0;
+                    q.ntiles = t.nbb; q.nrb = g.nu; q.nterm = G; q.kh = g.kh;
+                    q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
+                    hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(g.nu, 4), t.nbb), dim3(256), 0, stream, q);
+                    TD_LAUNCH_CHECK();
+                }
+            }
+        }
+        // gradient for the layer below: d x = W_ih^T d a, all steps at once
+        if (l > 0) {
+            for (int d = 0; d < D; ++d) {
+                TdFragGemmParams q;
+                q.wt = wT + (size_t)d * packT_dir + tg.hh_bytes;
+                q.in = ws + t.daf[l][d]; q.in_tile_off = 0; q.in_frags = 4 * g.kh;
+                q.out = ws + t.gout[l - 1][d]; q.out_frags = KT; q.out_off = 0;
+                q.ntiles = L * t.nbb; q.nrb = D * g.nu; q.nterm = G; q.kh = g.kh;
+                q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = 2; q.slab[3] = 3;
+                hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(D * g.nu, 4), L * t.nbb), dim3(256), 0, stream, q);
+                TD_LAUNCH_CHECK();
+            }
+        }
+        // weight and bias gradients
+        for (int d = 0; d < D; ++d) {
+            float *const *gw = grad_layer + (size_t)(l * D + d) * 4;
+            TD_REQUIRE(gw[0] && gw[1] && gw[2] && gw[3], "NULL gradient pointer for layer %d dir %d", l, d);
+            const __bf16 *dapl = (const __bf16 *)(ws + t.dapl[l][d]);
+            const int In = l == 0 ? cfg->c_in : DH;
+            for (int gate = 0; gate < G; ++gate) {
+                const int slab_x = gate, slab_h = (cfg->gru && gate == 2) ? 3 : gate;
+                TdDwParams q;
+                q.kchunk = 2048;
+                // W_ih
+                q.A = dapl + (size_t)slab_x * t.dapl_slab_elems; q.lda = t.cols;
+                q.B = (const __bf16 *)(ws + t.plain[l]); q.ldb = t.cols;
+                q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = H; q.K = (int)t.cols;
+                if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
+                else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
+                hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(g.nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
+                TD_LAUNCH_CHECK();
+                // W_hh: h_{t-1} is this direction's own output one step earlier in its processing order
+                if (L > 1) {
+                    const __bf16 *hpl = (const __bf16 *)(ws + t.plain[l + 1]) + (size_t)d * g.hpad * t.cols;
+                    const __bf16 *da_h = dapl + (size_t)slab_h * t.dapl_slab_elems;
+                    q.A = d == 0 ? da_h + t.Bp : da_h;
+                    q.B = d == 0 ? hpl : hpl + t.Bp;
+                    q.C = gw[1] + (size_t)gate * H * H; q.ldc = H; q.K = (int)(t.cols - t.Bp);
+                    q.N = g.hpad; q.hp = g.hpad; q.hv = H;
+                    hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(g.nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
+                    TD_LAUNCH_CHECK();
+                }
+                // biases
+                hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(H, 4)), dim3(256), 0, stream,
+                                   dapl + (size_t)slab_x * t.dapl_slab_elems, t.cols, H, t.cols, gw[2] + gate * H,
+                                   slab_h == slab_x ? gw[3] + gate * H : (float *)nullptr);
+                TD_LAUNCH_CHECK();
+                if (slab_h != slab_x) {
+                    hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(H, 4)), dim3(256), 0, stream,
+                                       dapl + (size_t)slab_h * t.dapl_slab_elems, t.cols, H, t.cols, gw[3] + gate * H, (float *)nullptr);
+                    TD_LAUNCH_CHECK();
+                }
+            }
+        }
+    }
+    return TD_OK;
+}

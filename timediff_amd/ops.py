@@ -52,6 +52,9 @@ class DenoiserKernels:
             raise _lib.TimediffError(lib().td_last_error().decode())
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._ws = None
+        self._train_ws = None
+        self._packT = None
+        self._packT_fresh = False
         self.refresh()
 
     def refresh(self):
@@ -60,6 +63,7 @@ class DenoiserKernels:
         self._misc = [_f32(self._sd[k]) for k in _lib.MISC_KEYS]
         self._misc_tab = ptr_table(self._misc)
         check(lib().td_rnn_pack_weights(C.byref(self.cfg), ptr_table(self._lw), ptr(self.packed), _stream()))
+        self._packT_fresh = False
 
     @property
     def misc_table(self):
@@ -94,6 +98,40 @@ class DenoiserKernels:
             check(lib().td_rnn_read_hidden(C.byref(self.cfg), ptr(ws), B, L, ptr(hidden), _stream()))
             return y, hidden
         return y
+
+
+    # -- training -------------------------------------------------------------------------------
+    def forward_train(self, x, film):
+        """Forward that keeps the activations for `backward` (one film row per batch element)."""
+        x, film = _f32(x), _f32(film)
+        B, _, L = x.shape
+        assert film.shape == (B, 2 * self.cfg.dirs * self.cfg.hidden)
+        need = lib().td_rnn_train_workspace_bytes(C.byref(self.cfg), B, L)
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = None
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        y = torch.empty(B, self.cfg.c_out, L, dtype=torch.float32, device=self.device)
+        check(lib().td_rnn_forward_train(C.byref(self.cfg), ptr(self.packed), self._misc_tab, ptr(x), ptr(film), B, L,
+                                         ptr(y), ptr(self._train_ws), _stream()))
+        self._train_shape = (B, L)
+        return y
+
+    def backward(self, grad_y, film):
+        """Backward of the last forward_train.  -> (layer grads in layer_keys order, {misc key: grad}, grad_film)."""
+        B, L = self._train_shape
+        grad_y, film = _f32(grad_y), _f32(film)
+        if not self._packT_fresh:
+            if self._packT is None:
+                self._packT = torch.empty(lib().td_rnn_packT_bytes(C.byref(self.cfg)), dtype=torch.uint8, device=self.device)
+            check(lib().td_rnn_pack_weights_T(C.byref(self.cfg), ptr_table(self._lw), ptr(self._packT), _stream()))
+            self._packT_fresh = True
+        g_layer = [torch.zeros_like(w) for w in self._lw]
+        g_misc = {k: torch.zeros_like(self._misc[i]) for i, k in enumerate(_lib.MISC_KEYS) if i >= 6}
+        tab = (C.c_void_p * _lib.TD_MISC_COUNT)(*[g_misc[k].data_ptr() if k in g_misc else None for k in _lib.MISC_KEYS])
+        g_film = torch.empty_like(film)
+        check(lib().td_rnn_backward(C.byref(self.cfg), ptr(self._packT), self._misc_tab, ptr(film), ptr(grad_y), B, L,
+                                    ptr(self._train_ws), ptr_table(g_layer), tab, ptr(g_film), _stream()))
+        return g_layer, g_misc, g_film
 
 
 class DiffusionKernels:
