@@ -214,6 +214,19 @@ TD_API int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_config *
  * No counterpart in the reference. */
 TD_API int td_sample_chain_release(void);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step of ETDiff.train (models/ETDiff/et_diff.py:239 clip_grad_norm_(1.0), :75/:247
+ * torch.optim.Adam(lr, betas), :254 EMA update) over FLAT fp32 buffers of all parameters.
+ *   td_grad_norm: norm[0] = || grad ||_2 (device scalar).
+ *   td_clip_adam_ema: g *= min(1, max_norm / (norm + 1e-6)) (skipped when max_norm <= 0), Adam with bias
+ *   correction for 1-based `step`, then ema_mode 0: EMA untouched, 1: ema = w, 2: ema = decay*ema + (1-decay)*w.
+ * ------------------------------------------------------------------------------------------ */
+TD_API size_t td_grad_norm_workspace_bytes(void);
+TD_API int td_grad_norm(const float *grad, size_t n, float *norm, void *workspace, void *stream);
+TD_API int td_clip_adam_ema(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, size_t n,
+                     const float *norm, float max_norm, float lr, float beta1, float beta2, float eps, int32_t step,
+                     int32_t ema_mode, float ema_decay, void *stream);
+
 /* Measurement aid, no counterpart in the reference: while enabled, every recurrent-layer kernel of the
  * widest kind (layers above the first) launched outside graph capture is bracketed by HIP events on
  * its own stream; td_profile_read waits for them and returns how many launches were timed and the sum

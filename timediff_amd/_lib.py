@@ -68,6 +68,10 @@ _SIGS = {
     "td_sample_chain": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(DiffusionConfig), _P, C.POINTER(_P), _P, _I, _P, _P,
                                   Rng, _I, _P, _P, _P]),
     "td_sample_chain_release": (C.c_int, []),
+    "td_grad_norm_workspace_bytes": (C.c_size_t, []),
+    "td_grad_norm": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
+    "td_clip_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, _I, _I, C.c_float, _P]),
     "td_profile_enable": (C.c_int, [_I]),
     "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
 }

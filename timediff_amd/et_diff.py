@@ -1,0 +1,254 @@
+"""ETDiff trainer with the reference's interface (models/ETDiff/et_diff.py:21-264): same constructor
+keywords, `.train()`, `.save_weights()`, `.load(path)`, `.ema.ema_model`, `.sample_min/.sample_max`,
+`.step`, and the same checkpoint dict {"diff_step", "diff_model", "opt", "ema", "scaler"}.
+
+What differs underneath (MI355X-first, same arithmetic):
+  * no accelerate / DDP wrappers: one process per GPU; with WORLD_SIZE > 1 the global batch is split
+    across ranks (split_batches=True semantics, et_diff.py:45) and the flat fp32 gradient buffer is
+    all-reduced (mean) over RCCL once per optimizer step, on a side stream;
+  * all parameters, gradients, Adam moments and EMA weights live in flat fp32 buffers: grad-norm, clip,
+    Adam and the EMA update are two fused kernel launches (td_grad_norm, td_clip_adam_ema);
+  * the loss is read back once per optimizer step, not once per micro-batch.
+EMA: the reference uses the third-party `ema_pytorch.EMA` (neither vendored nor version-pinned, so parity
+is unpinned); this class follows that package's documented defaults: no averaging until step 100
+(weights are copied), then decay = min(beta, 1 - (1 + (step - 101))^(-2/3)), applied every
+`update_every` optimizer steps; the "ema" sub-dict keeps the `ema_model.` key prefix.
+"""
+import copy
+import ctypes as C
+import logging
+import os
+import timeit
+
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader
+
+from . import _lib
+from ._lib import check, lib, ptr
+from .data import cycle, exists
+
+logging.basicConfig(filename=None, format="[%(levelname)s:%(asctime)s] %(message)s", level=logging.INFO)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _flatten_params_(module):
+    """Re-points every parameter of `module` into one contiguous fp32 buffer; returns (flat, params)."""
+    params = [p for p in module.parameters()]
+    flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view_as(p)
+        off += n
+    return flat, params
+
+
+class EMA(nn.Module):
+    """Exponential moving average of the diffusion module (interface of ema_pytorch.EMA as the reference
+    uses it: EMA(model, beta=, update_every=), .ema_model, .update(), state_dict with `ema_model.*`)."""
+
+    def __init__(self, model, beta=0.995, update_every=10, update_after_step=100, inv_gamma=1.0, power=2 / 3):
+        super().__init__()
+        self.beta, self.update_every, self.update_after_step = beta, update_every, update_after_step
+        self.inv_gamma, self.power = inv_gamma, power
+        self.ema_model = copy.deepcopy(model)
+        self.ema_model.requires_grad_(False)
+        self.register_buffer("initted", torch.tensor(False))
+        self.register_buffer("step", torch.tensor(0))
+
+    def current_decay(self, step):
+        epoch = max(step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        return min(max(1 - (1 + epoch / self.inv_gamma) ** -self.power, 0.0), self.beta)
+
+    def plan_update(self):
+        """Advances the step counter and says what this step does to the EMA weights:
+        (mode, decay) with mode 0 = nothing, 1 = copy the online weights, 2 = lerp."""
+        step = int(self.step.item()) + 1
+        self.step.fill_(step)
+        if step % self.update_every != 0:
+            return 0, 0.0
+        if step <= self.update_after_step or not bool(self.initted.item()):
+            self.initted.fill_(True)
+            return 1, 0.0
+        return 2, self.current_decay(step)
+
+
+class ETDiff(nn.Module):
+    def __init__(self, diffusion_model, dataset, *, train_batch_size=16, gradient_accumulate_every=1, diff_lr=1e-4,
+                 diff_num_steps=100000, ema_update_every=10, ema_decay=0.995, adam_betas=(0.9, 0.99),
+                 sample_every=1000, amp=False, mixed_precision_type="fp16", split_batches=True, wandb=None,
+                 check_point_path="results/checkpoint.pt", run_id=2023):
+        super().__init__()
+        if amp:
+            raise NotImplementedError("amp is hard-wired to False by the reference's CLI (etdiff_train.py:270)")
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise RuntimeError("ETDiff trains on the MI355X only (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        self._device = torch.device("cuda", local_rank)
+        if self.world > 1 and not torch.distributed.is_initialized():
+            torch.distributed.init_process_group("nccl", device_id=self._device)
+        print(f"*** Using device: {self._device} ***")
+
+        self.timer = timeit.default_timer
+        self.wandb = wandb
+        self.check_point_path = check_point_path
+        self.sample_min = dataset.min.numpy()
+        self.sample_max = dataset.max.numpy()
+
+        self.model = diffusion_model.to(self._device)
+        self.channels = diffusion_model.channels
+        self.sample_every = sample_every
+        self.batch_size = train_batch_size
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.diff_num_steps = diff_num_steps
+        self.run_id = run_id
+
+        # split_batches=True: train_batch_size is the global batch, every rank takes its slice
+        assert train_batch_size % self.world == 0, "global batch must divide evenly across ranks"
+        self.local_batch = train_batch_size // self.world
+        sampler = None
+        if self.world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, self.world, self.rank, shuffle=True, seed=run_id)
+        dl = DataLoader(dataset, batch_size=self.local_batch, shuffle=sampler is None, sampler=sampler, pin_memory=True,
+                        num_workers=1, drop_last=self.world > 1)
+        self.dl = cycle(dl)
+
+        # flat buffers: weights, gradients, Adam moments, EMA weights
+        self.lr, self.betas, self.eps = diff_lr, adam_betas, 1e-8
+        self.flat_param, self.params = _flatten_params_(self.model)
+        self.flat_grad = torch.zeros_like(self.flat_param)
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.ema = EMA(self.model, beta=ema_decay, update_every=ema_update_every)
+        self.ema.to(self._device)
+        self.flat_ema, _ = _flatten_params_(self.ema.ema_model)
+        self._norm = torch.zeros(1, dtype=torch.float32, device=self._device)
+        self._norm_ws = torch.empty(lib().td_grad_norm_workspace_bytes(), dtype=torch.uint8, device=self._device)
+        self._comm_stream = torch.cuda.Stream(device=self._device) if self.world > 1 else None
+        self.opt_step = 0
+        self.step = 0
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def is_main_process(self):
+        return self.rank == 0
+
+    # -- checkpoint (et_diff.py:91-105, :208-216) --------------------------------------------------
+    def _opt_state_dict(self):
+        """torch.optim.Adam.state_dict() layout, built from the flat moments."""
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.opt_step)),
+                        "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+            off += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.params)))}
+        return {"state": state if self.opt_step > 0 else {}, "param_groups": [group]}
+
+    def _load_opt_state_dict(self, sd):
+        off = 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            if i in sd["state"]:
+                st = sd["state"][i]
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self.opt_step = int(float(st["step"]))
+            off += n
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+
+    def save_weights(self):
+        weights = {"diff_step": self.step, "diff_model": self.model.state_dict(), "opt": self._opt_state_dict(),
+                   "ema": self.ema.state_dict(), "scaler": None}
+        torch.save(weights, self.check_point_path)
+
+    def load(self, path):
+        data = torch.load(path, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(data["diff_model"])     # copies into the flat buffer in place
+        self.step = data["diff_step"]
+        self._load_opt_state_dict(data["opt"])
+        self.ema.load_state_dict(data["ema"], strict=False)
+
+    # -- one optimizer step --------------------------------------------------------------------------
+    def _all_reduce_grads(self):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self.flat_grad.div_(self.world)
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def _optimizer_step(self, update_ema):
+        n = self.flat_param.numel()
+        check(lib().td_grad_norm(ptr(self.flat_grad), n, ptr(self._norm), ptr(self._norm_ws), _stream()))
+        self.opt_step += 1
+        mode, decay = self.ema.plan_update() if update_ema else (0, 0.0)
+        check(lib().td_clip_adam_ema(ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                     ptr(self.flat_ema), n, ptr(self._norm), 1.0, self.lr, self.betas[0], self.betas[1],
+                                     self.eps, self.opt_step, mode, decay, _stream()))
+        # in-place kernel writes do not bump torch's version counters: tell the denoisers their caches are stale
+        self._bump_versions()
+        self.flat_grad.zero_()
+
+    def _bump_versions(self):
+        for mod in (self.model, self.ema.ema_model):
+            den = getattr(mod, "model", None)
+            if den is not None and hasattr(den, "_kernels_version"):
+                den._kernels_version = None
+            if hasattr(mod, "_film_version"):
+                mod._film_version = None
+
+    def train_step(self):
+        """gradient_accumulate_every micro-batches + one optimizer step; -> the step's loss (device scalar)."""
+        ga = self.gradient_accumulate_every
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        for _ in range(ga):
+            data = next(self.dl).to(self.device, non_blocking=True)
+            loss = self.model(data) / ga
+            total += loss.detach()
+            loss.backward()
+        self._all_reduce_grads()
+        self._optimizer_step(update_ema=True)
+        self.step += 1
+        return total
+
+    def train(self):
+        from tqdm import tqdm
+        last_log = self.timer()
+        logging.info("********** START TRAINING DIFFUSION MODEL **********")
+        with tqdm(initial=self.step, total=self.diff_num_steps, disable=not self.is_main_process) as pbar:
+            while self.step < self.diff_num_steps:
+                total_loss = self.train_step().item()
+                pbar.set_description(f"loss: {total_loss:.4f}")
+                if exists(self.wandb) and self.timer() - last_log > 60:
+                    self.wandb.log({"total_loss": total_loss})
+                    last_log = self.timer()
+                if self.is_main_process and self.step != 0 and self.step % self.sample_every == 0:
+                    self.save_weights()
+                pbar.update(1)
+        if self.is_main_process:
+            self.save_weights()
+        print("========================= TRAINING COMPLETE =========================")
