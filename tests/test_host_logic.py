@@ -1,0 +1,145 @@
+"""CPU tests of the host side: CLI surface, module/buffer layout, EMA schedule, patient sharding and the
+world_size-2 (gloo) multi-process paths.  No kernel is launched here."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, sub
+
+
+def test_cli_defaults_match_reference():
+    """etdiff_train.py:32-148 of the reference: flag names and defaults."""
+    import etdiff_train as cli
+    a = cli.parse_arguments(["--check_point_path", "x.pt"])
+    want = dict(data_name="eicu", cut_length=272, hidden=256, num_layers=3, model="lstm", bidirectional=False,
+                batch_size=32, learning_rate=8e-5, embed_dim=64, time_dim=256, dropout=0, num_steps=700000,
+                gradient_accumulate_every=2, ema_decay=0.995, timesteps=1000, auto_normalize=True, record_every=10,
+                wandb=False, eval=False, seed=2023, loss_lambda=0.8, diff_type="mixed", dim=64)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    assert cli.COLUMNS_DICT["eicu"] == {"numerical": [0, 2, 4, 6], "categorical": [1, 3, 5, 7, 8],
+                                        "categorical_num_classes": [2] * 5}
+    assert cli.COLUMNS_DICT["mimiciii"]["categorical"] == [1, 3, 5, 7, 9, 11, 13, 14]
+    assert cli.model_path_to_sample_path("results/models/a.pt") == "results/samples/a_samples.npy"
+    with pytest.raises(SystemExit):
+        cli.parse_arguments([])            # --check_point_path is required
+    with pytest.raises(SystemExit):
+        cli.parse_arguments(["--check_point_path", "x", "--batch_size", "0"])
+
+
+def test_reference_import_paths_and_state_dict_layout():
+    """The names etdiff_train.py imports, and the checkpoint's `diff_model` keys in the reference's order."""
+    from models.ETDiff.blocks import RNN, EncoderDecoderRNN, NeuralCDE  # noqa: F401
+    from models.ETDiff.mixed_diffusion import MixedDiffusion
+    from models.ETDiff.utils import TimeSeriesDataset, cosine_beta_schedule, extract  # noqa: F401
+    g = load_golden("train_steps_eicu")
+    L, H, N, T, B, ga = [int(v) for v in g["cfg"]]
+    rnn = RNN(input_channels=14, hidden_channels=H, output_channels=14, layers=N, bidirectional=True)
+    diff = MixedDiffusion(rnn, seq_length=L, channels=14, numerical_features_indices=list(g["num_idx"]),
+                          categorical_features_indices=list(g["cat_idx"]), categorical_num_classes=list(g["K"]),
+                          timesteps=T, loss_lambda=0.8)
+    ref = sub(g, "init.")
+    sd = diff.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == v.shape and str(sd[k].dtype).endswith(str(v.dtype)), k
+        if not k.startswith("model."):
+            np.testing.assert_array_equal(sd[k].numpy(), v, err_msg=k)     # schedule buffers: bit-exact
+    assert diff.self_condition is False and diff.num_timesteps == T and diff.seq_length == L
+    with pytest.raises(ValueError):
+        MixedDiffusion(rnn, L, 14, [0], [1], [2], beta_schedule="sigmoid")
+    with pytest.raises(ValueError):
+        RNN(14, 8, 14, 1, model="rnn")
+    with pytest.raises(RuntimeError):
+        diff(torch.zeros(2, 9, L))          # no CPU fallback: the module must be on the GPU
+    with pytest.raises(AssertionError):
+        diff(torch.zeros(2, 9, L + 1))      # mixed_diffusion.py:405
+
+
+def test_ema_schedule():
+    """The warm-up rule documented in timediff_amd/et_diff.py (ema_pytorch defaults; parity unpinned)."""
+    from timediff_amd.et_diff import EMA
+    ema = EMA(torch.nn.Linear(2, 2), beta=0.995, update_every=10)
+    plan = [ema.plan_update() for _ in range(130)]
+    assert all(m == 0 for i, (m, _) in enumerate(plan, 1) if i % 10)
+    assert [plan[i - 1][0] for i in (10, 50, 100)] == [1, 1, 1]          # copies until step 100
+    assert plan[109][0] == 2 and abs(plan[109][1] - (1 - (1 + 9) ** (-2 / 3))) < 1e-12
+    assert plan[129][0] == 2 and plan[129][1] <= 0.995
+    assert ema.current_decay(10 ** 7) == 0.995
+    assert set(ema.state_dict()) == {"initted", "step", "ema_model.weight", "ema_model.bias"}
+
+
+def test_patient_shard_partition():
+    from timediff_amd.parallel import patient_shard
+    for total in (0, 1, 7, 20000, 1000000):
+        for world in (1, 2, 3, 8):
+            spans = [patient_shard(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from timediff_amd.parallel import all_reduce_mean_, gather_samples, patient_shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # data-parallel gradient exchange: mean of the ranks' flat buffers
+        flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        all_reduce_mean_(flat)
+        assert torch.allclose(flat, torch.arange(10, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+        # patient-sharded sampling: rank-local slices keyed by GLOBAL patient id reassemble on rank 0
+        total = 11
+        a, b = patient_shard(total, rank, world)
+        local = torch.arange(a, b, dtype=torch.float32)[:, None, None].expand(-1, 3, 4).contiguous()
+        full = gather_samples(local, total)
+        if rank == 0:
+            assert full.shape == (total, 3, 4)
+            assert torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32))
+        else:
+            assert full is None
+        dist.barrier()
+        out.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+def test_dataset_cache_roundtrip(tmp_path):
+    """TimeSeriesDataset (utils.py:10-51): NaN -> channel mean, min-max of the non-indicator channels, cache files."""
+    from timediff_amd.data import TimeSeriesDataset, reverse_normalize
+    torch.manual_seed(0)
+    raw = torch.rand(20, 4, 9) * 10 - 3
+    raw[:, 1, :] = (torch.rand(20, 9) > 0.5).float()
+    raw[3, 0, 2] = float("nan")
+    torch.save(raw, tmp_path / "raw.pt")
+    ds = TimeSeriesDataset("toy", [1], 8, load_path=str(tmp_path / "raw.pt"), root=str(tmp_path / "datasets"))
+    assert ds.data.shape == (20, 4, 8) and ds.channels == 4 and ds.seq_length == 8 and len(ds) == 20
+    assert torch.equal(ds.data[:, 1], raw[:, 1, :8])
+    num = ds.data[:, [0, 2, 3]]
+    assert num.min() >= 0 and num.max() <= 1 and not torch.isnan(ds.data).any()
+    again = TimeSeriesDataset("toy", [1], 8, root=str(tmp_path / "datasets"))
+    assert torch.equal(again.data, ds.data) and torch.equal(again.min, ds.min)
+    back = reverse_normalize(ds.data.numpy(), ds.min.numpy()[..., :1], ds.max.numpy()[..., :1])
+    ok = ~torch.isnan(raw[:, :, :8]).numpy()
+    np.testing.assert_allclose(back[:, [0, 2, 3]][ok[:, [0, 2, 3]]], raw[:, [0, 2, 3], :8].numpy()[ok[:, [0, 2, 3]]], rtol=1e-4,
+                               atol=1e-4)
