@@ -23,8 +23,8 @@
 // At a stage boundary a wave waits only for its own DMA pieces: s_waitcnt vmcnt(N) with N = the
 // number of younger vector-memory operations, counted from the same schedule tables that emit them.
 #pragma once
-#include "common.h"
-#include "rnn_layout.h"
+#include "../../timediff_amd/csrc/common.h"
+#include "../../timediff_amd/csrc/rnn_layout.h"
 
 #include <type_traits>
 
