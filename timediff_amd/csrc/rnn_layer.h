@@ -1,27 +1,33 @@
 // The persistent recurrent-layer kernel (one launch = one layer, both directions, all time steps).
 //
 // Decomposition: a workgroup = 4 waves, one wave per SIMD, each wave owns 32 sequences for the
-// whole sequence length: its cell state c (fp32) stays in registers, its hidden state h (bf16
-// B-fragments) in a private LDS region, so there is no cross-wave exchange of state and no grid
-// sync.  Per time step the gate pre-activations
+// whole sequence length: its cell state c (fp32, parked in AGPRs) and its hidden state h (bf16
+// B-fragments, VGPRs) never leave the register file, so there is no cross-wave exchange of state
+// and no grid sync.  Per time step the gate pre-activations
 //     gates^T[4H x 32] = [W_hh | W_ih] (A operand, bf16) x [h_{t-1} ; x_t]^T (B operand, bf16)
 // are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The weights do not fit one CU
-// (1.5 MiB per direction at H = 256), so they stream L2 -> LDS as a ring of two 32 KiB stages by
-// LDS-DMA (global_load_lds_dwordx4), shared by the four waves; forward and backward directions
-// run in different workgroups (even / odd blockIdx, i.e. on different XCDs, so each XCD's L2 holds
-// one direction's weights).
+// (1.5 MiB per direction at H = 256), so they stream L2 -> LDS through a ring of four 8 KiB
+// stages by LDS-DMA (global_load_lds_dwordx4), shared by the four waves; forward and backward
+// directions run in different workgroups (even / odd blockIdx, i.e. on different XCDs, so each
+// XCD's L2 holds one direction's weights).  The layer's input fragments of a step (32 KiB per wave
+// above the first layer) are needed once per 32-unit block, i.e. NU times per step: they are
+// brought into a private LDS region ONCE per step (also by LDS-DMA, one step ahead, fragment by
+// fragment as the last block retires them) instead of being re-streamed from L2 -- re-streaming
+// made the per-XCD working set (inputs 4 MiB + weights 1.5 MiB per step) larger than the 4 MiB L2
+// and 37 % of all L2 requests missed.
 //
 // Instruction schedule (all of it fixed at compile time, TdSched below).  One "slot" = one weight
 // fragment = one MFMA (two for the first layer's hi/lo products).  Around each MFMA the slot carries
 //   * the LDS read of the weight fragment APD slots ahead (register ring),
-//   * at most one LDS-DMA piece of the next stage (the 8 pieces a wave moves per stage are spread
-//     over the first half of the previous stage, so the texture path never sees a burst and every
-//     piece has >= 16 MFMAs to land),
-//   * the input-fragment loads of the layers above the first (register ring),
+//   * at most one LDS-DMA piece of the weight stage three stages ahead (a wave moves 2 pieces per
+//     stage, at positions 1 and 5, so the texture path never sees a burst and a piece has 24 MFMAs
+//     to land),
+//   * in the last block, the LDS-DMA piece that replaces a retired input fragment by the next step's,
 //   * a few instructions of the gate nonlinearities of the PREVIOUS 32-unit block (two accumulator
 //     sets alternate), so the exp/rcp work runs in the shadow of the matrix pipe.
-// At a stage boundary a wave waits only for its own DMA pieces: s_waitcnt vmcnt(N) with N = the
-// number of younger vector-memory operations, counted from the same schedule tables that emit them.
+// At a stage boundary a wave waits only for its own DMA pieces of that stage: s_waitcnt vmcnt(N)
+// with N = the number of younger vector-memory operations, counted from the same schedule tables
+// that emit them.
 #pragma once
 #include "common.h"
 #include "rnn_layout.h"
@@ -72,6 +78,10 @@ struct TdLayerParams {
     size_t save_dir_stride;  // floats
 };
 
+#define TD_RING_FRAGS 8   // weight fragments per ring stage
+#define TD_RING_DEPTH 4   // ring stages
+#define TD_RING_BYTES (TD_RING_FRAGS * TD_FRAG_BYTES)
+
 template <int NU, int KX, bool L0, bool GRU>
 struct TdLayerTraits {
     static constexpr int NG = GRU ? 3 : 4;
@@ -79,13 +89,13 @@ struct TdLayerTraits {
     static constexpr int XFR = L0 ? 2 * KX : KX;
     static constexpr int FU = 4 + (KH + XFR) * NG;  // 4 bias fragments lead each unit block
     static constexpr int NF = NU * FU;
-    static constexpr int NS = (NF + TD_STAGE_FRAGS - 1) / TD_STAGE_FRAGS;
-    static constexpr int LDS_W = 2 * TD_STAGE_BYTES;
-    static constexpr int LDS_H = TD_BLOCK_WAVES * KH * TD_FRAG_BYTES;
-    static constexpr int LDS_TOTAL = LDS_W + LDS_H;
-    static constexpr int XPD = L0 ? XFR : (KX < 8 ? KX : 8);  // input fragments in flight per wave
-    static constexpr int APD = 8;                              // weight fragments read ahead of their MFMA
-    static constexpr int PIECES = TD_STAGE_FRAGS / TD_BLOCK_WAVES;  // LDS-DMA pieces per wave and stage
+    static constexpr int NS = (NF + TD_RING_FRAGS - 1) / TD_RING_FRAGS;  // ring stages per time step
+    static constexpr int LDS_W = TD_RING_DEPTH * TD_RING_BYTES;
+    static constexpr int LDS_X = L0 ? 0 : TD_BLOCK_WAVES * KX * TD_FRAG_BYTES;  // this step's input fragments
+    static constexpr int LDS_TOTAL = LDS_W + LDS_X;
+    static constexpr int APD = 8;                                   // weight fragments read ahead of their MFMA
+    static constexpr int PIECES = TD_RING_FRAGS / TD_BLOCK_WAVES;  // LDS-DMA pieces per wave and stage
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -94,39 +104,40 @@ struct TdLayerTraits {
 template <int NU, int KX, bool L0, bool GRU, bool SAVE>
 struct TdSched {
     using T = TdLayerTraits<NU, KX, L0, GRU>;
-    static constexpr int NG = T::NG, KH = T::KH, FU = T::FU, NF = T::NF, NS = T::NS, APD = T::APD, XPD = T::XPD;
+    static constexpr int NG = T::NG, KH = T::KH, FU = T::FU, NF = T::NF, NS = T::NS, APD = T::APD;
     static constexpr int NOPS = GRU ? 7 : 12;  // gate-math micro-ops per accumulator row
     static constexpr int NQ = 16 * NOPS;       // per 32-unit block
+    static constexpr int LEAD = TD_RING_DEPTH - 1;  // pieces issued while stage j is read belong to stage j + LEAD
 
     // weight fragment whose LDS read is issued in slot F (-1: none)
     static constexpr int refill_of(int F) { return F + APD < NF ? F + APD : -1; }
-    static constexpr int stage_len(int j) { return j == NS - 1 ? NF - TD_STAGE_FRAGS * (NS - 1) : TD_STAGE_FRAGS; }
-    // piece i of the next stage is issued with the read of the fragment at position min(2i+1, len-1) of this stage
+    static constexpr int stage_len(int j) { return j == NS - 1 ? NF - TD_RING_FRAGS * (NS - 1) : TD_RING_FRAGS; }
+    // piece i goes out with the read of the fragment at position min(4i+1, len-1) of the stage being read
     static constexpr int piece_pos(int j, int i) {
         const int len = stage_len(j);
-        return 2 * i + 1 < len - 1 ? 2 * i + 1 : len - 1;
+        return 4 * i + 1 < len - 1 ? 4 * i + 1 : len - 1;
     }
-    static constexpr int dma_count(int R) {
+    static constexpr int wpieces(int F) {  // weight pieces issued in slot F
+        const int R = refill_of(F);
         if (R < 0) return 0;
         int n = 0;
-        for (int i = 0; i < T::PIECES; ++i) n += piece_pos(R / TD_STAGE_FRAGS, i) == R % TD_STAGE_FRAGS;
+        for (int i = 0; i < T::PIECES; ++i) n += piece_pos(R / TD_RING_FRAGS, i) == R % TD_RING_FRAGS;
         return n;
     }
-    // input-fragment loads issued in slot F (layers above the first; the first layer loads at the step's top)
-    static constexpr int xloads(int F) {
-        if (L0) return 0;
-        const int f = F % FU;
-        if (f == 0) return XPD;
-        const int x = f - 4 - KH * NG;
-        if (x < 0) return 0;
-        return (x % NG == NG - 1 && x / NG + XPD < KX) ? 1 : 0;
+    // input-fragment index whose LDS copy is replaced by the next step's in slot F (-1: none): the last block
+    // retires fragment kx with its last gate's MFMA
+    static constexpr int xdma_of(int F) {
+        if (L0 || F / FU != NU - 1) return -1;
+        const int x = F % FU - 4 - KH * NG;
+        if (x < 0) return -1;
+        return x % NG == NG - 1 ? x / NG : -1;
     }
+    static constexpr bool boundary(int F) { return refill_of(F) >= 0 && refill_of(F) % TD_RING_FRAGS == 0; }
     // room for gate-math micro-ops beside slot F's MFMA (block 0 of a step has no previous block to finish)
     static constexpr int capacity(int F) {
         if (F / FU == 0) return 0;
-        const int R = refill_of(F);
-        if (R >= 0 && R % TD_STAGE_FRAGS == 0) return 0;  // stage boundary: wait + barrier
-        if (dma_count(R) > 0 || xloads(F) > 0) return TD_CAP_VMEM;
+        if (boundary(F)) return 0;  // wait + barrier
+        if (wpieces(F) > 0 || xdma_of(F) >= 0) return TD_CAP_VMEM;
         return TD_CAP_FREE;
     }
     struct Tab {
@@ -146,16 +157,20 @@ struct TdSched {
                 t.qend[F] = total ? (short)((long)cum * NQ / total) : 0;
             }
         }
-        // Stage j >= 2 opens in slot Fb = 32j - APD; its last piece went out in slot Fl = Fb - 17 (position 15 of
-        // the full stage j-1).  Everything issued after that piece and before the wait is younger than every
-        // piece: the x loads and output stores of slot Fl (they follow the piece inside the slot) and of the
-        // slots in between.  Stages 0 and 1, training (SAVE) kernels and short steps wait for everything.
+        // Stage j opens in slot Fb = 8j - APD.  Its two pieces went out while stage j - LEAD (a full stage) was
+        // read, the second one in slot Fl = 8(j - LEAD) + 5 - APD.  Everything issued after that piece and
+        // before the wait is younger than both: inside slot Fl the input-fragment piece and the output stores
+        // (they follow the weight piece), then all vector-memory instructions of the slots in between.  Where the
+        // pieces came from the previous step or the prologue, and in training (SAVE) kernels, wait for everything.
         for (int j = 0; j < NS; ++j) {
             int n = 0;
-            const int Fb = TD_STAGE_FRAGS * j - APD, Fl = Fb - 17;
+            const int Fb = TD_RING_FRAGS * j - APD, Fl = TD_RING_FRAGS * (j - LEAD) + 5 - APD;
 #ifndef TD_WAIT_ALL
-            if (j >= 2 && !SAVE && Fl >= 0) {
-                for (int F = Fl; F < Fb; ++F) n += xloads(F) + ((t.qend[F] == NQ && t.qbeg[F] < NQ) ? 2 : 0);
+            if (j >= LEAD && !SAVE && Fl >= 0) {
+                for (int F = Fl; F < Fb; ++F) {
+                    const int st = (t.qend[F] == NQ && t.qbeg[F] < NQ) ? 2 : 0;
+                    n += (F > Fl ? wpieces(F) : 0) + (xdma_of(F) >= 0 ? 1 : 0) + st;
+                }
             }
 #endif
             t.waitn[j] = (short)(n > 60 ? 60 : n);
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
     using T = TdLayerTraits<NU, KX, L0, GRU>;
     using S = TdSched<NU, KX, L0, GRU, SAVE>;
     constexpr int NG = T::NG, KH = T::KH, XFR = T::XFR, FU = T::FU, NS = T::NS, NF = T::NF, APD = T::APD;
-    constexpr int NOPS = S::NOPS, NQ = S::NQ;
+    constexpr int NOPS = S::NOPS, NQ = S::NQ, LEAD = S::LEAD;
     __shared__ __attribute__((aligned(16))) char lds[T::LDS_TOTAL];
 
     const int tid = threadIdx.x;
@@ -186,30 +201,29 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
     const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    const char *wp = p.wpacked + (size_t)dir * p.dir_stride;
-    char *hreg = lds + T::LDS_W + wave * (KH * TD_FRAG_BYTES);
-    {
-        bf16x8 zero = {};
-#pragma unroll
-        for (int ks = 0; ks < KH; ++ks) *(bf16x8 *)(hreg + ks * TD_FRAG_BYTES + lane * 16) = zero;
-    }
-
-    // one stage = 32 fragments; every wave moves 8 of them, 1 KiB per instruction
-    // (scalar base + 32-bit lane offset: the address stays in SGPRs, nothing per-lane to keep live)
-    const unsigned lane16 = lane * 16;
-    const char *wwave = wp + (size_t)wave * T::PIECES * TD_FRAG_BYTES;
+    // LDS-DMA pieces (1 KiB = one fragment per wave-instruction; scalar base + 32-bit lane offset).
     // The piece is issued from inline asm: the compiler models an LDS-DMA load as a flat access to both LDS and
     // memory and then drains lgkmcnt AND vmcnt to zero at the next dependent instruction, which would stall the
-    // LDS read ring after every piece.  Written this way it does not know about the pieces; the waits it
-    // computes for the input-fragment loads are then merely stricter than needed (loads return in order), and
-    // the pieces themselves are covered by the counted wait at the stage boundary.  M0 (the LDS base of the
-    // DMA) is used by nothing else in this kernel.
-    const unsigned ldsw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + wave * T::PIECES * TD_FRAG_BYTES;
-    auto issue_piece = [&](const char *wsrc, int stage, int piece, int buf) {
-        const char *sp = wsrc + (size_t)stage * TD_STAGE_BYTES + piece * TD_FRAG_BYTES;
-        const unsigned dst = ldsw + buf * TD_STAGE_BYTES + piece * TD_FRAG_BYTES;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lane16), "s"(sp) : "memory");
+    // LDS read ring after every piece.  Written this way it does not know about the pieces; they are covered by
+    // the counted waits at the stage boundaries and the full wait at the top of every step.  M0 (the LDS base of
+    // the DMA) is used by nothing else in this kernel.
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    auto dma = [&](const char *src, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lane16), "s"(src) : "memory");
     };
+    // weights: ring stage j (any step) = fragments 8j .. 8j+7 of the packed stream, wave w moves 2w, 2w+1
+    const char *wwave = p.wpacked + (size_t)dir * p.dir_stride + (size_t)wave * T::PIECES * TD_FRAG_BYTES;
+    const unsigned ldsw = lds0 + wave * T::PIECES * TD_FRAG_BYTES;
+    auto issue_piece = [&](const char *wsrc, int stage, int piece, int buf) {
+        const char *sp = wsrc + (size_t)stage * TD_RING_BYTES + piece * TD_FRAG_BYTES;
+        asm volatile("" : "+s"(sp));
+        dma(sp, ldsw + buf * TD_RING_BYTES + piece * TD_FRAG_BYTES);
+    };
+    // inputs: this wave's private region, fragment kx at xlds + kx KiB
+    char *xreg = lds + T::LDS_W + wave * (KX * TD_FRAG_BYTES);
+    const unsigned ldsx = lds0 + T::LDS_W + wave * (KX * TD_FRAG_BYTES);
+    auto xrow = [&](int l) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
 
     float state[NU][16];  // LSTM: cell state c; GRU: hidden state h in fp32 (parked, see td_park)
 #pragma unroll
@@ -217,31 +231,47 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) state[u][r] = td_park(0.f);
 
-    // stage 0 of the first step
+    // prologue: the first LEAD weight stages and the first step's inputs
+    td_static_for<LEAD>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
 #pragma unroll
-    for (int i = 0; i < T::PIECES; ++i) issue_piece(wwave, 0, i, 0);
-    int bufsel = 1;  // toggled at every stage boundary; the first boundary selects buffer 0
+        for (int i = 0; i < T::PIECES; ++i) issue_piece(wwave, j % NS, i, j % TD_RING_DEPTH);
+    });
+    if constexpr (!L0) {
+        const char *x0 = xrow(dir ? p.L - 1 : 0);
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) dma(x0 + kx * TD_FRAG_BYTES, ldsx + kx * TD_FRAG_BYTES);
+    }
+    int ring = TD_RING_DEPTH - 1;  // buffer of the stage being read; advanced at every stage boundary
 
     // B operand of the bias k-step: ones at k = 0, 1 (the bias rides in as bf16 hi + lo columns)
     bf16x8 ones = {};
     if (lane < 32) { ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f; }
 
     f32x16 acc[2][4];  // two accumulator sets: block u accumulates into acc[u & 1] while block u-1's gates are finished
-    bf16x8 hn[KH];     // h_t of this step, written to LDS once every block has read h_{t-1}
+    bf16x8 hold[KH];   // h_{t-1}: B operand of the recurrent k-steps
+    bf16x8 hn[KH];     // h_t, becomes hold once every block has consumed h_{t-1}
     float T0[2][6];    // gate-math temporaries of the two rows in flight
     float hprev = 0.f;
+    {
+        bf16x8 zero = {};
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) hold[ks] = zero;
+    }
 
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
-        // input fragments of this step: layer 0 keeps its few in registers; above, every unit block
-        // re-streams them from L2 through a small register ring (holding all of them costs 128 VGPRs)
-        const bf16x8 *xp = (const bf16x8 *)(p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES) + lane;
-        bf16x8 xf[T::XPD];
+        const bool last_step = s + 1 == p.L;
+        // next step's inputs (the last step re-reads its own: the piece count per step stays fixed)
+        const char *xnext = xrow(last_step ? l : (dir ? l - 1 : l + 1));
+        asm volatile("" : "+s"(xnext));
+        // layer 0 keeps its few input fragments in registers
+        bf16x8 xf[L0 ? XFR : 1];
         if constexpr (L0) {
+            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
 #pragma unroll
             for (int i = 0; i < XFR; ++i) xf[i] = __builtin_nontemporal_load(xp + i * 64);
         }
-        const bool last_step = s + 1 == p.L;
         char *op = p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES + lane * 16;
         float *svb = nullptr;
         if constexpr (SAVE) svb = p.save + (size_t)dir * p.save_dir_stride + (((size_t)l * p.nbb + bb) * NU * 5) * 1024 + lane * 16;
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         // LDS read of weight fragment R of this step (+ what the schedule attaches to it)
         auto refill = [&](auto rc) -> bf16x8 {
             constexpr int R = decltype(rc)::value;
-            constexpr int stage = R / TD_STAGE_FRAGS, pos = R % TD_STAGE_FRAGS;
+            constexpr int stage = R / TD_RING_FRAGS, pos = R % TD_RING_FRAGS;
             if constexpr (pos == 0) {
                 // my pieces of `stage` have landed (younger loads/stores may stay in flight), my reads of the
                 // stage before are back; after the barrier that holds for every wave
@@ -262,23 +292,20 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WN) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                bufsel ^= 1;
+                ring = (ring + 1) & (TD_RING_DEPTH - 1);
             }
-            const bf16x8 a = *(const bf16x8 *)(lds + bufsel * TD_STAGE_BYTES + pos * TD_FRAG_BYTES + lane * 16);
-            if constexpr (S::dma_count(R) > 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                td_static_for<T::PIECES>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    if constexpr (S::piece_pos(stage, i) == pos) {
-                        if constexpr (stage + 1 < NS) issue_piece(wstep, stage + 1, i, bufsel ^ 1);
-                        else if (!last_step) issue_piece(wstep, 0, i, bufsel ^ 1);
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const bf16x8 a = *(const bf16x8 *)(lds + ring * TD_RING_BYTES + pos * TD_FRAG_BYTES + lane * 16);
+            td_static_for<T::PIECES>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (S::piece_pos(stage, i) == pos) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(wstep, (stage + LEAD) % NS, i, (ring + LEAD) & (TD_RING_DEPTH - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
             return a;
         };
-        auto hfrag = [&](int ks) -> bf16x8 { return *(const bf16x8 *)(hreg + ks * TD_FRAG_BYTES + lane * 16); };
+        auto xfrag = [&](int kx) -> bf16x8 { return *(const bf16x8 *)(xreg + kx * TD_FRAG_BYTES + lane * 16); };
 
         // micro-op q of block ub's gate nonlinearities; rows go in pairs so that the dependent exp -> rcp -> fma
         // chain of one row is separated by the other row's instructions.
@@ -339,18 +366,19 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 }
             }
             if constexpr (q == NQ - 1) {
-                // h_t of this block goes to HBM for the next layer right away (streaming: it must not push the
-                // weights out of this XCD's L2)
+                // h_t of this block goes to HBM for the next layer right away (streaming store: it must not push
+                // the weights out of this XCD's L2)
                 __builtin_nontemporal_store(hn[2 * ub], (bf16x8 *)(op + (2 * ub) * TD_FRAG_BYTES));
                 __builtin_nontemporal_store(hn[2 * ub + 1], (bf16x8 *)(op + (2 * ub + 1) * TD_FRAG_BYTES));
             }
         };
 
         // Weight fragments are read APD ahead of the MFMA that consumes them (LDS latency is ~100+ cycles,
-        // an MFMA 32): the ring A[] is statically indexed, so it lives in registers.
+        // an MFMA 32): the ring A[] is statically indexed, so it lives in registers.  The first read of a step
+        // opens stage 0 behind a full wait, which also covers this step's input pieces.
         bf16x8 A[APD];
         td_static_for<(APD < NF ? APD : NF)>([&](auto ic) { A[decltype(ic)::value] = refill(ic); });
-        bf16x8 hb[2];
+        bf16x8 xb[2];  // input fragments, read from LDS one k-step ahead
 
         td_static_for<NU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
@@ -358,23 +386,22 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 constexpr int f = decltype(fc)::value;
                 constexpr int F = u * FU + f;
                 if constexpr (f == 0) {
-                    hb[0] = hfrag(0);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[u & 1][g][r] = 0.f;
                 }
+                if constexpr (!L0 && f == 4 + KH * NG - 2) xb[0] = xfrag(0);
                 const bf16x8 a = A[F % APD];
                 f32x16(&ac)[4] = acc[u & 1];
                 if constexpr (f < 4) {
                     // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden)
                     ac[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, ac[f], 0, 0, 0);
                 } else if constexpr (f - 4 < KH * NG) {
-                    // recurrent part: h_{t-1} fragments from this wave's LDS region, one k-step ahead
+                    // recurrent part: h_{t-1} straight from registers
                     constexpr int ks = (f - 4) / NG, g = (f - 4) % NG;
-                    if constexpr (g == 0 && ks + 1 < KH) hb[(ks + 1) % 2] = hfrag(ks + 1);
                     constexpr int ai = (GRU && g == 2) ? 3 : g;
-                    ac[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[ks % 2], ac[ai], 0, 0, 0);
+                    ac[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hold[ks], ac[ai], 0, 0, 0);
                 } else if constexpr (L0) {
                     // first layer: W = Whi + Wlo, x = xhi + xlo in bf16; keep the three leading products
                     constexpr int x = f - 4 - KH * NG;
@@ -388,19 +415,17 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 } else {
                     constexpr int x = f - 4 - KH * NG;
                     constexpr int kx = x / NG, g = x % NG;
-                    ac[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[kx % T::XPD], ac[g], 0, 0, 0);
+                    if constexpr (g == 0 && kx + 1 < KX) xb[(kx + 1) % 2] = xfrag(kx + 1);
+                    ac[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[kx % 2], ac[g], 0, 0, 0);
                 }
                 if constexpr (S::refill_of(F) >= 0)
                     A[F % APD] = refill(std::integral_constant<int, (S::refill_of(F) >= 0 ? S::refill_of(F) : 0)>{});
-                // input fragments: the ring is primed at the block's first slot and refilled as fragments retire
-                if constexpr (!L0) {
-                    if constexpr (f == 0) {
-#pragma unroll
-                        for (int i = 0; i < T::XPD; ++i) xf[i] = __builtin_nontemporal_load(xp + i * 64);
-                    } else if constexpr (S::xloads(F) > 0) {
-                        constexpr int kx = (f - 4 - KH * NG) / NG;
-                        xf[kx % T::XPD] = __builtin_nontemporal_load(xp + (kx + T::XPD) * 64);
-                    }
+                // the last block retires input fragment kx: bring in the next step's
+                if constexpr (S::xdma_of(F) >= 0) {
+                    constexpr int kx = S::xdma_of(F) >= 0 ? S::xdma_of(F) : 0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma(xnext + kx * TD_FRAG_BYTES, ldsx + kx * TD_FRAG_BYTES);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // gate math of the previous block, in the shadow of this block's MFMAs
                 if constexpr (u > 0) {
@@ -419,10 +444,12 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         // the last block's gates have no MFMAs left to hide behind
         td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
 
-        // h_t replaces h_{t-1} in this wave's LDS region only now: every unit block above read the old one
+        // h_t replaces h_{t-1} only now: every unit block above consumed the old one
 #pragma unroll
-        for (int ks = 0; ks < KH; ++ks) *(bf16x8 *)(hreg + ks * TD_FRAG_BYTES + lane * 16) = hn[ks];
+        for (int ks = 0; ks < KH; ++ks) hold[ks] = hn[ks];
     }
+    // no LDS-DMA piece may still be in flight when the workgroup's LDS is handed on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TD_STAMP
     // diagnostic build only: in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz; the stamps go to a buffer nothing reads
     if (tid == 0) {
