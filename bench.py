@@ -174,10 +174,21 @@ def main():
         avg_s = ms.value / max(cnt.value, 1) * 1e-3
         flops_launch = B * D * 2.0 * L * 4 * H * (D * H + H)       # one launch = one layer, both directions
         achieved = flops_launch / avg_s / 1e12
+        # HBM traffic of that kernel per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); bench.py cannot collect counters itself, so it
+        # reports the committed measurement when it was taken at this batch size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "layer_kernel_pmc.json")) as f:
+                pm = json.load(f)
+            if pm.get("batch") == B and pm.get("seq_len") == L and pm.get("hidden") == H:
+                traffic = pm["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = dict(bound="mfma", kernel="td_rnn_layer_kernel<NU=8,KX=32,L0=0,GRU=0>", achieved=achieved,
                         peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK_TFLOPS,
-                        traffic=None, launches_timed=cnt.value, avg_launch_ms=avg_s * 1e3,
-                        flops_per_launch=flops_launch)
+                        traffic=traffic, traffic_unit="bytes per launch (PMC)", launches_timed=cnt.value,
+                        avg_launch_ms=avg_s * 1e3, flops_per_launch=flops_launch)
         base = None
         if not args.no_cpu_baseline:
             base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()})

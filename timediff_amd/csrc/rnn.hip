@@ -209,7 +209,16 @@ __global__ __launch_bounds__(256) void td_pack_input_kernel(const float *__restr
 
 // ---------------------------------------------------------------------------------------------
 // head: LayerNorm(D*H) -> FiLM -> fc -> (B, C_out, L)   (blocks.py:293-297, :340-341)
-// one wave per (l, batch block): lane (m, hf) holds half of sequence m's features.
+//
+// One wave per (batch block of 32 sequences, 4 consecutive positions).  The last layer's fragments of a
+// position are read ONCE into registers (KT x 16 B per lane); LayerNorm statistics are two register
+// passes (lanes m and m + 32 hold the two halves of sequence m); the normalised + FiLMed features stay in
+// fragment layout, which is exactly the B operand of v_mfma_f32_32x32x16_bf16, so the projection is
+//     y^T[32 (channels, padded) x 32 sequences] += fc_w[32 x 16] x feat[16 x 32]
+// with fc_w packed into A fragments in LDS once per workgroup.  Features and weights are both split into
+// bf16 hi + lo parts and the three leading products are kept, so the projection is fp32-accurate.  The four
+// positions' results are stored together as one 16-byte vector per (sequence, channel).
+// HBM traffic: the activations once (L*D*H*2 B per sequence) + the output.
 // ---------------------------------------------------------------------------------------------
 struct TdHeadParams {
     const char *act;  // last layer's fragments
@@ -219,84 +228,125 @@ struct TdHeadParams {
     int film_rows, B, L, nbb, H, hpad, kh, dirs, c_out;
 };
 
-template <int CMAX>
-__global__ __launch_bounds__(256) void td_head_kernel(TdHeadParams p) {
-    extern __shared__ __attribute__((aligned(16))) float hl[];
-    const int DHP = p.dirs * p.hpad, DH = p.dirs * p.H;
-    float *s_lnw = hl, *s_lnb = hl + DHP, *s_fcw = hl + 2 * DHP;  // fc_w as [c][DHP]
-    for (int i = threadIdx.x; i < DHP; i += 256) {
-        const int d = i / p.hpad, unit = i % p.hpad;
+template <int KT>
+__global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
+    // [KT][hi|lo] fc_w A-fragments, then four [KT*16] fp32 vectors in fragment order (k = 8 hf + j)
+    __shared__ __attribute__((aligned(16))) char hl[KT * 2 * TD_FRAG_BYTES + 3 * KT * 16 * sizeof(float)];
+    char *wfr = hl;
+    float *v_a = (float *)(hl + (size_t)KT * 2 * TD_FRAG_BYTES), *v_b = v_a + KT * 16, *v_msk = v_b + KT * 16;
+    const int DH = p.dirs * p.H;
+    const bool per_seq = !p.film_row && p.film_rows > 1;  // training: every sequence has its own time step
+    const float *film0 = p.film + (size_t)(p.film_row ? p.film_row[0] : 0) * 2 * DH;
+
+    for (int idx = threadIdx.x; idx < KT * 64 * 8; idx += 256) {
+        const int ks = idx / 512, ln = (idx % 512) / 8, j = idx % 8;
+        const int c = ln & 31, hf = ln >> 5;
+        const int d = ks / p.kh, unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+        const float w = (c < p.c_out && unit < p.H) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
+        const __bf16 hi = (__bf16)w;
+        ((__bf16 *)(wfr + (size_t)(2 * ks) * TD_FRAG_BYTES))[ln * 8 + j] = hi;
+        ((__bf16 *)(wfr + (size_t)(2 * ks + 1) * TD_FRAG_BYTES))[ln * 8 + j] = (__bf16)(w - (float)hi);
+    }
+    for (int idx = threadIdx.x; idx < KT * 16; idx += 256) {
+        const int ks = idx / 16, hf = (idx % 16) / 8, j = idx % 8;
+        const int d = ks / p.kh, unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
         const bool ok = unit < p.H;
-        s_lnw[i] = ok ? p.ln_w[d * p.H + unit] : 0.f;
-        s_lnb[i] = ok ? p.ln_b[d * p.H + unit] : 0.f;
-        for (int c = 0; c < CMAX; ++c) s_fcw[c * DHP + i] = (ok && c < p.c_out) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
+        const int feat = d * p.H + (ok ? unit : 0);
+        const float lw = ok ? p.ln_w[feat] : 0.f, lb = ok ? p.ln_b[feat] : 0.f;
+        if (per_seq) {
+            v_a[idx] = lw; v_b[idx] = lb;
+        } else {  // y = xhat * ln_w * (scale + 1) + ln_b * (scale + 1) + shift
+            const float sc = ok ? film0[feat] + 1.0f : 0.f, sh = ok ? film0[DH + feat] : 0.f;
+            v_a[idx] = lw * sc; v_b[idx] = lb * sc + sh;
+        }
+        v_msk[idx] = ok ? 1.f : 0.f;
     }
     __syncthreads();
+
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
-    const int KT = p.dirs * p.kh;
-    const size_t ntask = (size_t)p.L * p.nbb;
-    for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
-        const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
+    const int L4 = (p.L + 3) / 4;
+    const size_t ngroup = (size_t)L4 * p.nbb;
+    const bool vec_ok = (p.L & 3) == 0;
+    for (size_t grp = (size_t)blockIdx.x * 4 + wave; grp < ngroup; grp += (size_t)gridDim.x * 4) {
+        const int l4 = (int)(grp / p.nbb), bblk = (int)(grp % p.nbb);
         const int b = bblk * 32 + m;
-        const bf16x8 *fp = (const bf16x8 *)(p.act + task * KT * TD_FRAG_BYTES) + lane;
-        // pass 1: mean
-        float sum = 0.f;
-        for (int ks = 0; ks < KT; ++ks) {
-            const bf16x8 v = fp[ks * 64];
+        const float *filmb = p.film + (size_t)(b < p.B ? b : 0) * 2 * DH;
+        f32x16 acc[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += (float)v[j];  // padded units hold exact zeros
-        }
-        sum += __shfl_xor(sum, 32);
-        const float mu = sum / (float)DH;
-        float sq = 0.f;
-        for (int ks = 0; ks < KT; ++ks) {
-            const bf16x8 v = fp[ks * 64];
-            const int unit0 = 16 * (ks % p.kh) + 4 * hf;
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * l4 + i;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int unit = unit0 + 8 * (j >> 2) + (j & 3);
-                const float dlt = (float)v[j] - mu;
-                sq += unit < p.H ? dlt * dlt : 0.f;
-            }
-        }
-        sq += __shfl_xor(sq, 32);
-        const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
-        const int frow = p.film_row ? p.film_row[0] : (p.film_rows > 1 ? (b < p.B ? b : 0) : 0);
-        const float *film = p.film + (size_t)frow * 2 * DH;
-        float acc[CMAX];
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            if (l >= p.L) continue;
+            const bf16x8 *fp = (const bf16x8 *)(p.act + ((size_t)l * p.nbb + bblk) * KT * TD_FRAG_BYTES) + lane;
+            bf16x8 v[KT];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
-        for (int ks = 0; ks < KT; ++ks) {
-            const bf16x8 v = fp[ks * 64];
-            const int d = ks / p.kh;
+            for (int ks = 0; ks < KT; ++ks) v[ks] = __builtin_nontemporal_load(fp + ks * 64);
+            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int unit0 = 16 * (ks % p.kh) + 8 * q + 4 * hf;  // 4 consecutive units
-                const int ip = d * p.hpad + unit0;
-                const f32x4 w4 = *(const f32x4 *)(s_lnw + ip), b4 = *(const f32x4 *)(s_lnb + ip);
-                float yv[4];
+            for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int unit = unit0 + e;
-                    const bool ok = unit < p.H;
-                    const int feat = d * p.H + (ok ? unit : 0);
-                    const float scale = ok ? film[feat] : 0.f, shift = ok ? film[DH + feat] : 0.f;
-                    const float xh = ((float)v[4 * q + e] - mu) * rstd;
-                    yv[e] = ok ? (xh * w4[e] + b4[e]) * (scale + 1.0f) + shift : 0.f;
-                }
+                for (int j = 0; j < 8; ++j) sum += (float)v[ks][j];  // padded units hold exact zeros
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum / (float)DH;
+            float sq = 0.f;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    const f32x4 f4 = *(const f32x4 *)(s_fcw + c * DHP + ip);
-                    acc[c] += f4[0] * yv[0] + f4[1] * yv[1] + f4[2] * yv[2] + f4[3] * yv[3];
+            for (int ks = 0; ks < KT; ++ks) {
+                const f32x4 m0 = *(const f32x4 *)(v_msk + ks * 16 + hf * 8), m1 = *(const f32x4 *)(v_msk + ks * 16 + hf * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dlt = ((float)v[ks][j] - mu) * (j < 4 ? m0[j & 3] : m1[j & 3]);
+                    sq = fmaf(dlt, dlt, sq);
                 }
             }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                const f32x4 a0 = *(const f32x4 *)(v_a + ks * 16 + hf * 8), a1 = *(const f32x4 *)(v_a + ks * 16 + hf * 8 + 4);
+                const f32x4 b0 = *(const f32x4 *)(v_b + ks * 16 + hf * 8), b1 = *(const f32x4 *)(v_b + ks * 16 + hf * 8 + 4);
+                bf16x8 yh, yl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float av = j < 4 ? a0[j & 3] : a1[j & 3], bv = j < 4 ? b0[j & 3] : b1[j & 3];
+                    if (per_seq) {
+                        const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+                        const bool ok = unit < p.H;
+                        const int feat = (ks / p.kh) * p.H + (ok ? unit : 0);
+                        const float sc = ok ? filmb[feat] + 1.0f : 0.f, sh = ok ? filmb[DH + feat] : 0.f;
+                        bv = bv * sc + sh;
+                        av = av * sc;
+                    }
+                    const float yv = ((float)v[ks][j] - mu) * rstd * av + bv;
+                    const __bf16 h = (__bf16)yv;
+                    yh[j] = h;
+                    yl[j] = (__bf16)(yv - (float)h);
+                }
+                const bf16x8 wh = *(const bf16x8 *)(wfr + (size_t)(2 * ks) * TD_FRAG_BYTES + lane * 16);
+                const bf16x8 wl = *(const bf16x8 *)(wfr + (size_t)(2 * ks + 1) * TD_FRAG_BYTES + lane * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, yh, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh, acc[i], 0, 0, 0);
+            }
         }
+        // accumulator row r of lane (m, hf) = channel (r&3) + 8(r>>2) + 4hf of sequence m
+        if (b < p.B) {
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) acc[c] += __shfl_xor(acc[c], 32);
-        if (hf == 0 && b < p.B) {
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (c < p.c_out) {
+                    const float bias = p.fc_b[c];
+                    float *yo = p.y + ((size_t)b * p.c_out + c) * p.L + 4 * l4;
+                    if (vec_ok) {
+                        f32x4 o = {acc[0][r] + bias, acc[1][r] + bias, acc[2][r] + bias, acc[3][r] + bias};
+                        *(f32x4 *)yo = o;
+                    } else {
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < p.c_out) p.y[((size_t)b * p.c_out + c) * p.L + l] = acc[c] + p.fc_b[c];
+                        for (int i = 0; i < 4; ++i)
+                            if (4 * l4 + i < p.L) yo[i] = acc[i][r] + bias;
+                    }
+                }
+            }
         }
     }
 }
@@ -318,11 +368,10 @@ __global__ void td_unpack_hidden_kernel(const char *act, float *hidden, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// layer dispatch (templates in rnn_launch.h; the SAVE = true instantiations live in rnn_train.hip)
+// layer dispatch (one translation unit per kernel family: rnn_launch.h, rnn_layer_inst.hip)
 // ---------------------------------------------------------------------------------------------
 int td_launch_layer_infer(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    return gru ? td_launch_layer_any<true, false>(nu, p, layer0, kxsel, stream)
-               : td_launch_layer_any<false, false>(nu, p, layer0, kxsel, stream);
+    return td_launch_layer_dispatch(gru, 0, nu, p, layer0, kxsel, stream);
 }
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
 
@@ -383,6 +432,16 @@ int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float 
     return td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, stream);
 }
 
+template <int KT>
+static int td_launch_head(const TdHeadParams &p, hipStream_t stream) {
+    const size_t ngroup = (size_t)((p.L + 3) / 4) * p.nbb;
+    int blocks = (int)((ngroup + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(td_head_kernel<KT>, dim3(blocks), dim3(256), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
                 const int32_t *film_row, int batch, int L, float *y, hipStream_t stream) {
     TdRnnGeom g;
@@ -394,20 +453,18 @@ int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *
     p.film = film; p.film_row = film_row; p.film_rows = film_rows;
     p.y = y; p.B = batch; p.L = L; p.nbb = td_cdiv(batch, TD_WAVE_BATCH);
     p.H = cfg->hidden; p.hpad = g.hpad; p.kh = g.kh; p.dirs = g.dirs; p.c_out = cfg->c_out;
-    const size_t ntask = (size_t)L * p.nbb;
-    int blocks = (int)((ntask + 3) / 4);
-    if (blocks > 2048) blocks = 2048;
-    const int DHP = g.dirs * g.hpad;
-    if (cfg->c_out <= 16) {
-        size_t shm = (size_t)(2 + 16) * DHP * sizeof(float);
-        hipLaunchKernelGGL(td_head_kernel<16>, dim3(blocks), dim3(256), shm, stream, p);
-    } else {
-        size_t shm = (size_t)(2 + 32) * DHP * sizeof(float);
-        TD_HIP(hipFuncSetAttribute((const void *)td_head_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(td_head_kernel<32>, dim3(blocks), dim3(256), shm, stream, p);
+    switch (g.dirs * g.kh) {
+        case 2: return td_launch_head<2>(p, stream);
+        case 4: return td_launch_head<4>(p, stream);
+        case 6: return td_launch_head<6>(p, stream);
+        case 8: return td_launch_head<8>(p, stream);
+        case 12: return td_launch_head<12>(p, stream);
+        case 16: return td_launch_head<16>(p, stream);
+        case 24: return td_launch_head<24>(p, stream);
+        case 32: return td_launch_head<32>(p, stream);
     }
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+    td_set_error("unsupported fragment count %d in the head", g.dirs * g.kh);
+    return TD_ERR_UNSUPPORTED;
 }
 
 extern "C" int td_rnn_forward(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,

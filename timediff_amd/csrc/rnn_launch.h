@@ -1,37 +1,70 @@
 // Dispatch from runtime (hidden block count, input k-steps, layer kind, cell) to the instantiated
-// recurrent-layer kernels.  Included by rnn.hip (inference kernels) and rnn_train.hip (SAVE kernels).
+// recurrent-layer kernels.  Every (hidden block count, cell, training) combination is its own translation
+// unit (rnn_layer_inst.hip compiled with -DTD_INST_NU/-DTD_INST_GRU/-DTD_INST_SAVE): the kernels are fully
+// unrolled over one time step, and one file with all 96 of them takes the better part of an hour to compile.
 #pragma once
-#include "rnn_layer.h"
+#include "common.h"
+#include "rnn_params.h"
 
-template <int NU, int KX, bool L0, bool GRU, bool SAVE>
-static int td_launch_layer(const TdLayerParams &p, hipStream_t stream) {
-    const int tiles = td_cdiv(p.nbb, TD_BLOCK_WAVES);
-    hipLaunchKernelGGL((td_rnn_layer_kernel<NU, KX, L0, GRU, SAVE>), dim3(tiles * p.dirs), dim3(256), 0, stream, p);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
-}
+int td_launch_layer_nu1_g0_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu2_g0_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu3_g0_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu4_g0_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu6_g0_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu8_g0_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu1_g1_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu2_g1_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu3_g1_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu4_g1_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu6_g1_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu8_g1_s0(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu1_g0_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu2_g0_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu3_g0_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu4_g0_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu6_g0_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu8_g0_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu1_g1_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu2_g1_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu3_g1_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu4_g1_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu6_g1_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+int td_launch_layer_nu8_g1_s1(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
 
-template <int NU, bool GRU, bool SAVE>
-static int td_launch_layer_nu(const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    if (layer0) {
-        if (kxsel == 1) return td_launch_layer<NU, 1, true, GRU, SAVE>(p, stream);
-        return td_launch_layer<NU, 2, true, GRU, SAVE>(p, stream);
+static inline int td_launch_layer_dispatch(int gru, int save, int nu, const TdLayerParams &p, bool layer0, int kxsel,
+                                           hipStream_t stream) {
+    if (!gru && !save) switch (nu) {
+        case 1: return td_launch_layer_nu1_g0_s0(p, layer0, kxsel, stream);
+        case 2: return td_launch_layer_nu2_g0_s0(p, layer0, kxsel, stream);
+        case 3: return td_launch_layer_nu3_g0_s0(p, layer0, kxsel, stream);
+        case 4: return td_launch_layer_nu4_g0_s0(p, layer0, kxsel, stream);
+        case 6: return td_launch_layer_nu6_g0_s0(p, layer0, kxsel, stream);
+        case 8: return td_launch_layer_nu8_g0_s0(p, layer0, kxsel, stream);
     }
-    if (kxsel == 1) return td_launch_layer<NU, 2 * NU, false, GRU, SAVE>(p, stream);
-    return td_launch_layer<NU, 4 * NU, false, GRU, SAVE>(p, stream);
-}
-
-template <bool GRU, bool SAVE>
-static int td_launch_layer_any(int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    switch (nu) {
-        case 1: return td_launch_layer_nu<1, GRU, SAVE>(p, layer0, kxsel, stream);
-        case 2: return td_launch_layer_nu<2, GRU, SAVE>(p, layer0, kxsel, stream);
-        case 3: return td_launch_layer_nu<3, GRU, SAVE>(p, layer0, kxsel, stream);
-        case 4: return td_launch_layer_nu<4, GRU, SAVE>(p, layer0, kxsel, stream);
-        case 6: return td_launch_layer_nu<6, GRU, SAVE>(p, layer0, kxsel, stream);
-        case 8: return td_launch_layer_nu<8, GRU, SAVE>(p, layer0, kxsel, stream);
+    if (gru && !save) switch (nu) {
+        case 1: return td_launch_layer_nu1_g1_s0(p, layer0, kxsel, stream);
+        case 2: return td_launch_layer_nu2_g1_s0(p, layer0, kxsel, stream);
+        case 3: return td_launch_layer_nu3_g1_s0(p, layer0, kxsel, stream);
+        case 4: return td_launch_layer_nu4_g1_s0(p, layer0, kxsel, stream);
+        case 6: return td_launch_layer_nu6_g1_s0(p, layer0, kxsel, stream);
+        case 8: return td_launch_layer_nu8_g1_s0(p, layer0, kxsel, stream);
+    }
+    if (!gru && save) switch (nu) {
+        case 1: return td_launch_layer_nu1_g0_s1(p, layer0, kxsel, stream);
+        case 2: return td_launch_layer_nu2_g0_s1(p, layer0, kxsel, stream);
+        case 3: return td_launch_layer_nu3_g0_s1(p, layer0, kxsel, stream);
+        case 4: return td_launch_layer_nu4_g0_s1(p, layer0, kxsel, stream);
+        case 6: return td_launch_layer_nu6_g0_s1(p, layer0, kxsel, stream);
+        case 8: return td_launch_layer_nu8_g0_s1(p, layer0, kxsel, stream);
+    }
+    if (gru && save) switch (nu) {
+        case 1: return td_launch_layer_nu1_g1_s1(p, layer0, kxsel, stream);
+        case 2: return td_launch_layer_nu2_g1_s1(p, layer0, kxsel, stream);
+        case 3: return td_launch_layer_nu3_g1_s1(p, layer0, kxsel, stream);
+        case 4: return td_launch_layer_nu4_g1_s1(p, layer0, kxsel, stream);
+        case 6: return td_launch_layer_nu6_g1_s1(p, layer0, kxsel, stream);
+        case 8: return td_launch_layer_nu8_g1_s1(p, layer0, kxsel, stream);
     }
     td_set_error("unsupported hidden block count %d", nu);
     return TD_ERR_UNSUPPORTED;
 }
-

@@ -31,6 +31,7 @@
 #pragma once
 #include "common.h"
 #include "rnn_layout.h"
+#include "rnn_params.h"
 
 #include <type_traits>
 
@@ -65,18 +66,6 @@ __device__ __forceinline__ float td_unpark(float a) {
     return v;
 }
 
-struct TdLayerParams {
-    const char *wpacked;  // packed weights of this layer, direction 0
-    size_t dir_stride;    // bytes to direction 1
-    const char *xin;      // input fragments  [l][bblk][in_frags][64][8] bf16
-    char *out;            // output fragments [l][bblk][out_frags][64][8] bf16
-    int in_frags, out_frags;
-    int L, nbb, dirs;
-    // training only (SAVE kernels): gate activations and state for the backward pass,
-    // [dir][l][bblk][u][5][64 lanes][16] fp32 in accumulator layout: LSTM i,f,g,o,c ; GRU r,z,n,(W_hn h + b_hn),h
-    float *save;
-    size_t save_dir_stride;  // floats
-};
 
 #define TD_RING_FRAGS 8   // weight fragments per ring stage
 #define TD_RING_DEPTH 4   // ring stages
@@ -107,15 +96,20 @@ struct TdSched {
     static constexpr int NG = T::NG, KH = T::KH, FU = T::FU, NF = T::NF, NS = T::NS, APD = T::APD;
     static constexpr int NOPS = GRU ? 7 : 12;  // gate-math micro-ops per accumulator row
     static constexpr int NQ = 16 * NOPS;       // per 32-unit block
-    static constexpr int LEAD = TD_RING_DEPTH - 1;  // pieces issued while stage j is read belong to stage j + LEAD
+    // Pieces issued while stage j is read belong to stage j + LEAD and land in the buffer stage j - 2 was read
+    // from.  Every read of stage j - 2 has been consumed by an MFMA issued before stage j opens (the register
+    // ring holds 8 = one stage of fragments), so no wave needs to drain its LDS reads at the boundary.
+    static constexpr int LEAD = TD_RING_DEPTH - 2;
+    static constexpr int PIECE_STEP = 2;  // pieces go out at positions 1, 3
+    static_assert(T::APD <= TD_RING_FRAGS, "the LDS read ring must not reach back two stages");
 
     // weight fragment whose LDS read is issued in slot F (-1: none)
     static constexpr int refill_of(int F) { return F + APD < NF ? F + APD : -1; }
     static constexpr int stage_len(int j) { return j == NS - 1 ? NF - TD_RING_FRAGS * (NS - 1) : TD_RING_FRAGS; }
-    // piece i goes out with the read of the fragment at position min(4i+1, len-1) of the stage being read
+    // piece i goes out with the read of the fragment at position min(2i+1, len-1) of the stage being read
     static constexpr int piece_pos(int j, int i) {
         const int len = stage_len(j);
-        return 4 * i + 1 < len - 1 ? 4 * i + 1 : len - 1;
+        return PIECE_STEP * i + 1 < len - 1 ? PIECE_STEP * i + 1 : len - 1;
     }
     static constexpr int wpieces(int F) {  // weight pieces issued in slot F
         const int R = refill_of(F);
@@ -158,13 +152,13 @@ struct TdSched {
             }
         }
         // Stage j opens in slot Fb = 8j - APD.  Its two pieces went out while stage j - LEAD (a full stage) was
-        // read, the second one in slot Fl = 8(j - LEAD) + 5 - APD.  Everything issued after that piece and
+        // read, the second one in slot Fl = 8(j - LEAD) + 3 - APD.  Everything issued after that piece and
         // before the wait is younger than both: inside slot Fl the input-fragment piece and the output stores
         // (they follow the weight piece), then all vector-memory instructions of the slots in between.  Where the
         // pieces came from the previous step or the prologue, and in training (SAVE) kernels, wait for everything.
         for (int j = 0; j < NS; ++j) {
             int n = 0;
-            const int Fb = TD_RING_FRAGS * j - APD, Fl = TD_RING_FRAGS * (j - LEAD) + 5 - APD;
+            const int Fb = TD_RING_FRAGS * j - APD, Fl = TD_RING_FRAGS * (j - LEAD) + PIECE_STEP + 1 - APD;
 #ifndef TD_WAIT_ALL
             if (j >= LEAD && !SAVE && Fl >= 0) {
                 for (int F = Fl; F < Fb; ++F) {
@@ -286,10 +280,10 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             constexpr int R = decltype(rc)::value;
             constexpr int stage = R / TD_RING_FRAGS, pos = R % TD_RING_FRAGS;
             if constexpr (pos == 0) {
-                // my pieces of `stage` have landed (younger loads/stores may stay in flight), my reads of the
-                // stage before are back; after the barrier that holds for every wave
+                // my pieces of `stage` have landed (younger loads/stores may stay in flight); after the barrier
+                // that holds for every wave, and every wave is done with the buffer the next pieces go to
                 constexpr int WN = S::tab.waitn[stage];
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WN) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 ring = (ring + 1) & (TD_RING_DEPTH - 1);

@@ -14,8 +14,7 @@
 #include "rnn_launch.h"
 
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    return gru ? td_launch_layer_any<true, true>(nu, p, layer0, kxsel, stream)
-               : td_launch_layer_any<false, true>(nu, p, layer0, kxsel, stream);
+    return td_launch_layer_dispatch(gru, 1, nu, p, layer0, kxsel, stream);
 }
 
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
