@@ -210,14 +210,13 @@ __global__ __launch_bounds__(256) void td_pack_input_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------------
 // head: LayerNorm(D*H) -> FiLM -> fc -> (B, C_out, L)   (blocks.py:293-297, :340-341)
 //
-// One wave per (batch block of 32 sequences, 4 consecutive positions).  The last layer's fragments of a
+// One wave per (position, batch block of 32 sequences).  The last layer's fragments of a
 // position are read ONCE into registers (KT x 16 B per lane); LayerNorm statistics are two register
 // passes (lanes m and m + 32 hold the two halves of sequence m); the normalised + FiLMed features stay in
 // fragment layout, which is exactly the B operand of v_mfma_f32_32x32x16_bf16, so the projection is
 //     y^T[32 (channels, padded) x 32 sequences] += fc_w[32 x 16] x feat[16 x 32]
 // with fc_w packed into A fragments in LDS once per workgroup.  Features and weights are both split into
-// bf16 hi + lo parts and the three leading products are kept, so the projection is fp32-accurate.  The four
-// positions' results are stored together as one 16-byte vector per (sequence, channel).
+// bf16 hi + lo parts and the three leading products are kept, so the projection is fp32-accurate.
 // HBM traffic: the activations once (L*D*H*2 B per sequence) + the output.
 // ---------------------------------------------------------------------------------------------
 struct TdHeadParams {
@@ -228,14 +227,14 @@ struct TdHeadParams {
     int film_rows, B, L, nbb, H, hpad, kh, dirs, c_out;
 };
 
-template <int KT>
+template <int KT, bool PER_SEQ>
 __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
-    // [KT][hi|lo] fc_w A-fragments, then four [KT*16] fp32 vectors in fragment order (k = 8 hf + j)
+    // [KT][hi|lo] fc_w A-fragments, then three [KT*16] fp32 vectors in fragment order (k = 8 hf + j)
     __shared__ __attribute__((aligned(16))) char hl[KT * 2 * TD_FRAG_BYTES + 3 * KT * 16 * sizeof(float)];
     char *wfr = hl;
     float *v_a = (float *)(hl + (size_t)KT * 2 * TD_FRAG_BYTES), *v_b = v_a + KT * 16, *v_msk = v_b + KT * 16;
     const int DH = p.dirs * p.H;
-    const bool per_seq = !p.film_row && p.film_rows > 1;  // training: every sequence has its own time step
+    // PER_SEQ (training): every sequence has its own time step, i.e. its own FiLM row
     const float *film0 = p.film + (size_t)(p.film_row ? p.film_row[0] : 0) * 2 * DH;
 
     for (int idx = threadIdx.x; idx < KT * 64 * 8; idx += 256) {
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
         const bool ok = unit < p.H;
         const int feat = d * p.H + (ok ? unit : 0);
         const float lw = ok ? p.ln_w[feat] : 0.f, lb = ok ? p.ln_b[feat] : 0.f;
-        if (per_seq) {
+        if (PER_SEQ) {
             v_a[idx] = lw; v_b[idx] = lb;
         } else {  // y = xhat * ln_w * (scale + 1) + ln_b * (scale + 1) + shift
             const float sc = ok ? film0[feat] + 1.0f : 0.f, sh = ok ? film0[DH + feat] : 0.f;
@@ -264,88 +263,81 @@ __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
-    const int L4 = (p.L + 3) / 4;
-    const size_t ngroup = (size_t)L4 * p.nbb;
-    const bool vec_ok = (p.L & 3) == 0;
-    for (size_t grp = (size_t)blockIdx.x * 4 + wave; grp < ngroup; grp += (size_t)gridDim.x * 4) {
-        const int l4 = (int)(grp / p.nbb), bblk = (int)(grp % p.nbb);
+    const size_t ntask = (size_t)p.L * p.nbb;
+#pragma unroll 1
+    for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
+        const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
         const int b = bblk * 32 + m;
         const float *filmb = p.film + (size_t)(b < p.B ? b : 0) * 2 * DH;
-        f32x16 acc[4];
+        const bf16x8 *fp = (const bf16x8 *)(p.act + task * KT * TD_FRAG_BYTES) + lane;
+        // the per-feature vectors are re-read from LDS for every task: hoisted out of the task loop they would
+        // need 24 * KT registers per lane
+        const float *va = v_a + hf * 8, *vb = v_b + hf * 8, *vm = v_msk + hf * 8;
+        const char *wf = wfr + lane * 16;
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(vm), "+v"(wf));
+        bf16x8 v[KT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = 4 * l4 + i;
+        for (int ks = 0; ks < KT; ++ks) v[ks] = __builtin_nontemporal_load(fp + ks * 64);
+        float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            if (l >= p.L) continue;
-            const bf16x8 *fp = (const bf16x8 *)(p.act + ((size_t)l * p.nbb + bblk) * KT * TD_FRAG_BYTES) + lane;
-            bf16x8 v[KT];
+        for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) v[ks] = __builtin_nontemporal_load(fp + ks * 64);
-            float sum = 0.f;
+            for (int j = 0; j < 8; ++j) sum += (float)v[ks][j];  // padded units hold exact zeros
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum / (float)DH;
+        float sq = 0.f;
+        // each pass unpacks the bf16 values again: kept unpacked across passes they would need 8 * KT registers
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks)
+        for (int ks = 0; ks < KT; ++ks) asm volatile("" : "+v"(v[ks]));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sum += (float)v[ks][j];  // padded units hold exact zeros
-            sum += __shfl_xor(sum, 32);
-            const float mu = sum / (float)DH;
-            float sq = 0.f;
+        for (int ks = 0; ks < KT; ++ks) {
+            const f32x4 m0 = *(const f32x4 *)(vm + ks * 16), m1 = *(const f32x4 *)(vm + ks * 16 + 4);
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
-                const f32x4 m0 = *(const f32x4 *)(v_msk + ks * 16 + hf * 8), m1 = *(const f32x4 *)(v_msk + ks * 16 + hf * 8 + 4);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float dlt = ((float)v[ks][j] - mu) * (j < 4 ? m0[j & 3] : m1[j & 3]);
-                    sq = fmaf(dlt, dlt, sq);
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = ((float)v[ks][j] - mu) * (j < 4 ? m0[j & 3] : m1[j & 3]);
+                sq = fmaf(dlt, dlt, sq);
             }
-            sq += __shfl_xor(sq, 32);
-            const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
+        }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
+        f32x16 acc;
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
-                const f32x4 a0 = *(const f32x4 *)(v_a + ks * 16 + hf * 8), a1 = *(const f32x4 *)(v_a + ks * 16 + hf * 8 + 4);
-                const f32x4 b0 = *(const f32x4 *)(v_b + ks * 16 + hf * 8), b1 = *(const f32x4 *)(v_b + ks * 16 + hf * 8 + 4);
-                bf16x8 yh, yl;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float av = j < 4 ? a0[j & 3] : a1[j & 3], bv = j < 4 ? b0[j & 3] : b1[j & 3];
-                    if (per_seq) {
-                        const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
-                        const bool ok = unit < p.H;
-                        const int feat = (ks / p.kh) * p.H + (ok ? unit : 0);
-                        const float sc = ok ? filmb[feat] + 1.0f : 0.f, sh = ok ? filmb[DH + feat] : 0.f;
-                        bv = bv * sc + sh;
-                        av = av * sc;
-                    }
-                    const float yv = ((float)v[ks][j] - mu) * rstd * av + bv;
-                    const __bf16 h = (__bf16)yv;
-                    yh[j] = h;
-                    yl[j] = (__bf16)(yv - (float)h);
+        for (int ks = 0; ks < KT; ++ks) asm volatile("" : "+v"(v[ks]));
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            const f32x4 a0 = *(const f32x4 *)(va + ks * 16), a1 = *(const f32x4 *)(va + ks * 16 + 4);
+            const f32x4 b0 = *(const f32x4 *)(vb + ks * 16), b1 = *(const f32x4 *)(vb + ks * 16 + 4);
+            bf16x8 yh, yl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float av = j < 4 ? a0[j & 3] : a1[j & 3], bv = j < 4 ? b0[j & 3] : b1[j & 3];
+                if constexpr (PER_SEQ) {
+                    const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+                    const int feat = (ks / p.kh) * p.H + (unit < p.H ? unit : 0);
+                    const float sc = filmb[feat] + 1.0f, sh = filmb[DH + feat];  // padded units: av = bv = 0, mask below
+                    const float mk = vm[ks * 16 + j];
+                    bv = (bv * sc + sh) * mk;
+                    av = av * sc;
                 }
-                const bf16x8 wh = *(const bf16x8 *)(wfr + (size_t)(2 * ks) * TD_FRAG_BYTES + lane * 16);
-                const bf16x8 wl = *(const bf16x8 *)(wfr + (size_t)(2 * ks + 1) * TD_FRAG_BYTES + lane * 16);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, yh, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh, acc[i], 0, 0, 0);
+                const float yv = ((float)v[ks][j] - mu) * rstd * av + bv;
+                const __bf16 h = (__bf16)yv;
+                yh[j] = h;
+                yl[j] = (__bf16)(yv - (float)h);
             }
+            const bf16x8 wh = *(const bf16x8 *)(wf + (size_t)(2 * ks) * TD_FRAG_BYTES);
+            const bf16x8 wl = *(const bf16x8 *)(wf + (size_t)(2 * ks + 1) * TD_FRAG_BYTES);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, yh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh, acc, 0, 0, 0);
         }
         // accumulator row r of lane (m, hf) = channel (r&3) + 8(r>>2) + 4hf of sequence m
         if (b < p.B) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (c < p.c_out) {
-                    const float bias = p.fc_b[c];
-                    float *yo = p.y + ((size_t)b * p.c_out + c) * p.L + 4 * l4;
-                    if (vec_ok) {
-                        f32x4 o = {acc[0][r] + bias, acc[1][r] + bias, acc[2][r] + bias, acc[3][r] + bias};
-                        *(f32x4 *)yo = o;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (4 * l4 + i < p.L) yo[i] = acc[i][r] + bias;
-                    }
-                }
+                if (c < p.c_out) p.y[((size_t)b * p.c_out + c) * p.L + l] = acc[r] + p.fc_b[c];
             }
         }
     }
@@ -434,10 +426,11 @@ int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float 
 
 template <int KT>
 static int td_launch_head(const TdHeadParams &p, hipStream_t stream) {
-    const size_t ngroup = (size_t)((p.L + 3) / 4) * p.nbb;
-    int blocks = (int)((ngroup + 3) / 4);
+    const size_t ntask = (size_t)p.L * p.nbb;
+    int blocks = (int)((ntask + 3) / 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(td_head_kernel<KT>, dim3(blocks), dim3(256), 0, stream, p);
+    if (!p.film_row && p.film_rows > 1) hipLaunchKernelGGL((td_head_kernel<KT, true>), dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((td_head_kernel<KT, false>), dim3(blocks), dim3(256), 0, stream, p);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
