@@ -91,6 +91,43 @@ def cpu_baseline(sd, cols, L, T, tables, seconds_target=15.0):
                        f"{per_step:.2f} s/step, extrapolated to T={T}")
 
 
+def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup):
+    """Second half of BASELINE.json's metric: optimizer steps / second of the ETDiff training loop
+    (et_diff.py:226-261: ga micro-batches of MixedDiffusion.forward + backward, clip, Adam, EMA) on synthetic
+    eICU-shaped data, through the same module interface the reference's CLI uses."""
+    from models.ETDiff.blocks import RNN
+    from models.ETDiff.et_diff import ETDiff
+    from models.ETDiff.mixed_diffusion import MixedDiffusion
+    from timediff_amd.data import TensorSeriesDataset
+    torch.manual_seed(2023)
+    width = len(cols["num"]) + sum(cols["K"])
+    C = len(cols["num"]) + len(cols["cat"])
+    rnn = RNN(input_channels=width, hidden_channels=H, output_channels=width, layers=N, model="lstm", bidirectional=True)
+    diff = MixedDiffusion(rnn, seq_length=L, channels=width, numerical_features_indices=cols["num"],
+                          categorical_features_indices=cols["cat"], categorical_num_classes=cols["K"], timesteps=T,
+                          loss_lambda=0.8)
+    g = torch.Generator().manual_seed(2023)
+    data = torch.rand(max(4 * batch, 256), C, L, generator=g)
+    for c in cols["cat"]:
+        data[:, c] = (data[:, c] > 0.5).float()
+    et = ETDiff(diff, TensorSeriesDataset(data, cols["cat"]), train_batch_size=batch, gradient_accumulate_every=ga,
+                diff_lr=8e-5, diff_num_steps=steps, ema_update_every=10, check_point_path="/tmp/bench_ckpt.pt")
+    for _ in range(warmup):
+        et.train_step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        loss = et.train_step()
+    torch.cuda.synchronize()
+    el = time.time() - t0
+    assert torch.isfinite(loss).all()
+    return dict(value=steps / el, unit="optimizer steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
+                config=dict(workload=f"ETDiff eICU-shaped training step: global batch {batch}, grad-accum {ga}, L={L}, "
+                                     f"3-layer bidirectional LSTM H={H}, T={T}, Adam + clip + EMA",
+                            batch=batch, gradient_accumulate_every=ga),
+                sequences_per_s=steps * batch * ga / el, final_loss=float(loss))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +139,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=272)
     ap.add_argument("--probe-steps", type=int, default=8, help="eager reverse steps timed with HIP events for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-probe", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=32, help="training probe: batch per micro-batch (reference default 32)")
+    ap.add_argument("--train-steps", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,6 +232,12 @@ def main():
         base = None
         if not args.no_cpu_baseline:
             base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()})
+        train = None
+        if world == 1 and not args.no_train_probe:
+            del out, z, idx, mo
+            torch.cuda.empty_cache()
+            train = {"reference_batch": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 2),
+                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 3, 1)}
         fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
         result = {
             "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,
@@ -203,7 +249,7 @@ def main():
                        "batch_per_gpu": B, "sequences_per_step": world * B, "parallelism": f"patient-sharded x{world}",
                        "graph": True},
             "denoiser_tflops_whole_chain": value * fl / 1e12,
-            "roofline": roofline, "cpu_baseline": base,
+            "roofline": roofline, "cpu_baseline": base, "train": train,
         }
     if world > 1:
         dist.barrier()
