@@ -126,6 +126,12 @@ struct TdSched {
         if (x < 0) return -1;
         return x % NG == NG - 1 ? x / NG : -1;
     }
+    // training kernels: vector stores issued by micro-op q (the gate values of 4 accumulator rows go out
+    // together, 5 quantities x 16 B per lane, with the op that completes the second row pair)
+    static constexpr int save_stores(int q) {
+        const int pair = q / (2 * NOPS), w = q % (2 * NOPS);
+        return (SAVE && (pair & 1) && (w & 1) && w / 2 == (GRU ? 6 : 8)) ? 5 : 0;
+    }
     static constexpr bool boundary(int F) { return refill_of(F) >= 0 && refill_of(F) % TD_RING_FRAGS == 0; }
     // room for gate-math micro-ops beside slot F's MFMA (block 0 of a step has no previous block to finish)
     static constexpr int capacity(int F) {
@@ -155,14 +161,15 @@ struct TdSched {
         // read, the second one in slot Fl = 8(j - LEAD) + 3 - APD.  Everything issued after that piece and
         // before the wait is younger than both: inside slot Fl the input-fragment piece and the output stores
         // (they follow the weight piece), then all vector-memory instructions of the slots in between.  Where the
-        // pieces came from the previous step or the prologue, and in training (SAVE) kernels, wait for everything.
+        // pieces came from the previous step or the prologue, wait for everything.
         for (int j = 0; j < NS; ++j) {
             int n = 0;
             const int Fb = TD_RING_FRAGS * j - APD, Fl = TD_RING_FRAGS * (j - LEAD) + PIECE_STEP + 1 - APD;
 #ifndef TD_WAIT_ALL
-            if (j >= LEAD && !SAVE && Fl >= 0) {
+            if (j >= LEAD && Fl >= 0) {
                 for (int F = Fl; F < Fb; ++F) {
-                    const int st = (t.qend[F] == NQ && t.qbeg[F] < NQ) ? 2 : 0;
+                    int st = (t.qend[F] == NQ && t.qbeg[F] < NQ) ? 2 : 0;
+                    for (int q = t.qbeg[F]; q < t.qend[F]; ++q) st += save_stores(q);
                     n += (F > Fl ? wpieces(F) : 0) + (xdma_of(F) >= 0 ? 1 : 0) + st;
                 }
             }
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
     bf16x8 hold[KH];   // h_{t-1}: B operand of the recurrent k-steps
     bf16x8 hn[KH];     // h_t, becomes hold once every block has consumed h_{t-1}
     float T0[2][6];    // gate-math temporaries of the two rows in flight
+    f32x4 sbuf[5];     // training: saved gate values of four accumulator rows, stored together
     float hprev = 0.f;
     {
         bf16x8 zero = {};
@@ -326,8 +334,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     state[ub][r] = td_park(cv);
                     t[4] = cv;
                     if constexpr (SAVE) {
-                        float *svp = svb + (size_t)ub * 5 * 1024;
-                        svp[r] = t[0]; svp[1024 + r] = t[1]; svp[2048 + r] = gg; svp[3072 + r] = t[3]; svp[4096 + r] = cv;
+                        sbuf[0][r & 3] = t[0]; sbuf[1][r & 3] = t[1]; sbuf[2][r & 3] = gg; sbuf[3][r & 3] = t[3]; sbuf[4][r & 3] = cv;
                     }
                 }
                 if constexpr (o == 9) t[5] = __builtin_amdgcn_exp2f(P2L2E * t[4]);
@@ -345,11 +352,16 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     const float h = (1.0f - t[1]) * ng + t[1] * td_unpark(state[ub][r]);
                     state[ub][r] = td_park(h);
                     if constexpr (SAVE) {
-                        float *svp = svb + (size_t)ub * 5 * 1024;
-                        svp[r] = t[0]; svp[1024 + r] = t[1]; svp[2048 + r] = ng; svp[3072 + r] = a[3][r]; svp[4096 + r] = h;
+                        sbuf[0][r & 3] = t[0]; sbuf[1][r & 3] = t[1]; sbuf[2][r & 3] = ng; sbuf[3][r & 3] = a[3][r]; sbuf[4][r & 3] = h;
                     }
                     hval = h;
                 }
+            }
+            if constexpr (S::save_stores(q) > 0) {
+                // rows r-3 .. r are complete: one 16-byte store per saved quantity
+                float *svp = svb + (size_t)ub * 5 * 1024 + (r & ~3);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) *(f32x4 *)(svp + k * 1024) = sbuf[k];
             }
             if constexpr (o == NOPS - 1) {
                 // rows r-1, r are neighbours in the bf16 fragment: convert them as a pair

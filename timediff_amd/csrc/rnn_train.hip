@@ -1,12 +1,11 @@
 // Denoiser training path: forward that keeps what the backward pass needs, and the backward pass
 // (autograd of models/ETDiff/blocks.py:333-341 as run by accelerator.backward, et_diff.py:237).
 //
-// Backward decomposition (first version: correct and parallel at the reference's small training
-// batches; the sweep is a launch per time step, not yet a persistent kernel):
+// Backward decomposition:
 //   head_bwd      d y -> d h_top (bf16 fragments), d film, d LayerNorm, d fc           (one pass, LDS atomics)
 //   per layer, top down:
-//     bptt_point  per step: gate-gradient arithmetic, d a_t as MFMA fragments + plain rows
-//     frag_gemm   per step: d h_{t-1} = W_hh^T d a_t          (MFMA, accumulator -> operand trick)
+//     bptt_sweep  ONE launch for all steps: gate-gradient arithmetic (d a_t as MFMA fragments + plain rows) and
+//                 d h_{t-1} = W_hh^T d a_t on MFMA, state in registers, d a_t exchanged through LDS
 //     frag_gemm   all steps at once: d x = W_ih^T d a         (gradient for the layer below)
 //     dw_gemm     d W = d a . [x ; h_prev]^T over all (sequence, step) columns   (MFMA, split-K, fp32 atomics)
 //     bias_reduce d b = row sums of d a
@@ -489,6 +488,118 @@ __global__ __launch_bounds__(256) void td_frag_gemm_kernel(TdFragGemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// BPTT sweep of one layer: the whole time loop in ONE launch.  A workgroup owns one batch block of 32
+// sequences in one direction; wave u (of 8) owns the 32-unit block u: its d c carry and its
+// d h_{t-1} (the accumulator of the recurrent GEMM, which is already in the layout the gate-gradient
+// arithmetic works in) stay in its registers across steps.  Per step the waves publish d a_t as MFMA
+// B fragments in LDS (double buffered: one barrier per step) and each computes
+//     d h_{t-1}[its row blocks] = W_hh^T (A fragments, L2-resident) x d a_t
+// d a_t also goes to HBM in both layouts the batched GEMMs after the sweep read (d x = W_ih^T d a, d W).
+// ---------------------------------------------------------------------------------------------
+struct TdSweepParams {
+    TdBpttParams b;          // b.s unused
+    const char *wt;          // W_hh^T fragments [rb][nterm][kh], direction 0
+    size_t wt_dir;           // bytes to direction 1
+    int nterm;
+    int slab[4];
+};
+
+__global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const TdBpttParams &p = q.b;
+    const int bblk = blockIdx.x, d = blockIdx.y;
+    const int u = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, m = lane & 31;   // wave = unit block
+    const bool mine = u < p.nu;
+    const size_t stage_bytes = (size_t)4 * p.kh * TD_FRAG_BYTES;
+    const size_t cols = (size_t)p.L * p.nbb * 32;
+    const int hpad = p.kh * 16;
+    f32x4 dh[4], carry[4];   // accumulator rows 4k .. 4k+3
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { dh[k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const bf16x8 *wp = (const bf16x8 *)(q.wt + (size_t)d * q.wt_dir + (size_t)(mine ? u : 0) * q.nterm * p.kh * TD_FRAG_BYTES) + lane;
+
+    for (int s = 0; s < p.L; ++s) {
+        const int pos = p.L - 1 - s;                   // position in the direction's forward order
+        const int l = d ? p.L - 1 - pos : pos;
+        const int lprev = d ? l + 1 : l - 1;           // the step processed before l in the forward pass
+        const bool has_prev = pos > 0;
+        char *dab = sm + (size_t)(s & 1) * stage_bytes;
+        if (mine) {
+            for (int sidx = 0; sidx < p.n_src; ++sidx) {
+                const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+                const bf16x8 a = gp[0], b = gp[64];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { dh[j >> 2][j & 3] += (float)a[j]; dh[2 + (j >> 2)][j & 3] += (float)b[j]; }
+            }
+            const f32x4 *sv = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16);
+            const f32x4 *svp = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16);
+            float da[4][16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 s0 = sv[k], s1 = sv[256 + k], s2 = sv[512 + k], s3 = sv[768 + k], s4 = sv[1024 + k];
+                const f32x4 pv = has_prev ? svp[k] : f32x4{0.f, 0.f, 0.f, 0.f};   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * k + e;
+                    const float g = dh[k][e], prev = pv[e];
+                    if (!p.gru) {
+                        const float ig = s0[e], fg = s1[e], gg = s2[e], og = s3[e], cv = s4[e];
+                        const float tc = td_tanh(cv);
+                        const float dcv = carry[k][e] + g * og * (1.0f - tc * tc);
+                        da[0][r] = dcv * gg * ig * (1.0f - ig);
+                        da[1][r] = dcv * prev * fg * (1.0f - fg);
+                        da[2][r] = dcv * ig * (1.0f - gg * gg);
+                        da[3][r] = g * tc * og * (1.0f - og);
+                        carry[k][e] = dcv * fg;
+                    } else {
+                        const float rg = s0[e], zg = s1[e], ng = s2[e], hn = s3[e];
+                        const float dht = g + carry[k][e];
+                        const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
+                        da[0][r] = dan * hn * rg * (1.0f - rg);
+                        da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
+                        da[2][r] = dan;
+                        da[3][r] = dan * rg;
+                        carry[k][e] = dht * zg;
+                    }
+                }
+            }
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                bf16x8 a, b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a[j] = (__bf16)da[gi][j]; b[j] = (__bf16)da[gi][8 + j]; }
+                bf16x8 *lp = (bf16x8 *)(dab + ((size_t)gi * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+                lp[0] = a;
+                lp[64] = b;
+                bf16x8 *fp = (bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+                fp[0] = a;
+                fp[64] = b;
+                __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int unit = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    pl[(size_t)unit * cols] = r < 8 ? a[r] : b[r - 8];
+                }
+            }
+        }
+        __syncthreads();   // d a_t of every unit block is in LDS (the other buffer is free again two steps on)
+        if (mine && s + 1 < p.L) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int term = 0; term < q.nterm; ++term) {
+                const bf16x8 *bp = (const bf16x8 *)(dab + (size_t)q.slab[term] * p.kh * TD_FRAG_BYTES) + lane;
+                const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
+#pragma unroll 16
+                for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[r >> 2][r & 3] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight-gradient GEMM: C[m][col(n)] += sum_k A[m][k] B[n][k]   (bf16 operands, fp32 atomics, split K)
 // ---------------------------------------------------------------------------------------------
 struct TdDwParams {
@@ -597,32 +708,21 @@ extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, cons
         const int n_src = l == N - 1 ? 1 : D;
         const size_t packT_dir = tg.hh_bytes + (l > 0 ? tg.ih_bytes : 0);
         const char *wT = (const char *)packT + tg.layer_off[l];
-        for (int s = 0; s < L; ++s) {
-            TdBpttParams p;
+        {
+            TdSweepParams q;
+            TdBpttParams &p = q.b;
             p.gsrc[0] = ws + t.gout[l][0]; p.gsrc[1] = ws + t.gout[l][1]; p.n_src = n_src;
-            p.dhrec = ws + t.dhrec[0]; p.dhrec_dir = t.dhrec[1] - t.dhrec[0];
-            p.dc = (float *)(ws + t.dc[0]); p.dc_dir = (t.dc[1] - t.dc[0]) / sizeof(float);
+            p.dhrec = nullptr; p.dhrec_dir = 0; p.dc = nullptr; p.dc_dir = 0;
             p.save = (const float *)(ws + t.save[l]); p.save_dir = t.save_dir_floats;
             p.daf = ws + t.daf[l][0]; p.daf_dir = D > 1 ? t.daf[l][1] - t.daf[l][0] : 0;
             p.dapl = (__bf16 *)(ws + t.dapl[l][0]); p.dapl_dir = D > 1 ? (t.dapl[l][1] - t.dapl[l][0]) / 2 : 0;
-            p.s = s; p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
-            hipLaunchKernelGGL(td_bptt_point_kernel, dim3(g.nu, t.nbb, D), dim3(64), 0, stream, p);
+            p.s = 0; p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
+            q.wt = wT; q.wt_dir = packT_dir; q.nterm = G;
+            q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
+            const size_t shm = (size_t)2 * 4 * g.kh * TD_FRAG_BYTES;
+            TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(td_bptt_sweep_kernel, dim3(t.nbb, D), dim3(512), shm, stream, q);
             TD_LAUNCH_CHECK();
-            if (s + 1 < L) {
-                for (int d = 0; d < D; ++d) {
-                    const int pos = L - 1 - s, lt = d ? L - 1 - pos : pos;
-                    TdFragGemmParams q;
-                    q.wt = wT + (size_t)d * packT_dir;
-                    q.in = ws + t.daf[l][d];
-                    q.in_tile_off = (size_t)lt * t.nbb * 4 * g.kh;
-                    q.in_frags = 4 * g.kh;
-                    q.out = ws + t.dhrec[d]; q.out_frags = g.kh; q.out_off = 0;
-                    q.ntiles = t.nbb; q.nrb = g.nu; q.nterm = G; q.kh = g.kh;
-                    q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
-                    hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(g.nu, 4), t.nbb), dim3(256), 0, stream, q);
-                    TD_LAUNCH_CHECK();
-                }
-            }
         }
         // gradient for the layer below: d x = W_ih^T d a, all steps at once
         if (l > 0) {
