@@ -266,3 +266,46 @@ def test_denoiser_backward(name, dev):
     # d film against the oracle's chain: grad of time_mlp.1.bias is the batch sum of d film
     np.testing.assert_allclose(g_film.sum(0).cpu().numpy(), g["grad.rnn.time_mlp.1.bias"], rtol=3e-2,
                                atol=3e-2 * np.abs(g["grad.rnn.time_mlp.1.bias"]).max())
+
+
+def _random_eicu_state(H, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / np.sqrt(H)
+    sd = {}
+    for l in range(3):
+        for sfx in ("", "_reverse"):
+            In = C if l == 0 else 2 * H
+            sd[f"rnn.rnn.weight_ih_l{l}{sfx}"] = (torch.rand(4 * H, In, generator=g) * 2 - 1) * k
+            sd[f"rnn.rnn.weight_hh_l{l}{sfx}"] = (torch.rand(4 * H, H, generator=g) * 2 - 1) * k
+            sd[f"rnn.rnn.bias_ih_l{l}{sfx}"] = (torch.rand(4 * H, generator=g) * 2 - 1) * k
+            sd[f"rnn.rnn.bias_hh_l{l}{sfx}"] = (torch.rand(4 * H, generator=g) * 2 - 1) * k
+    sd["time_emb.1.weight"] = torch.randn(256, 64, generator=g) / 8; sd["time_emb.1.bias"] = torch.zeros(256)
+    sd["time_emb.3.weight"] = torch.randn(256, 256, generator=g) / 16; sd["time_emb.3.bias"] = torch.zeros(256)
+    sd["rnn.time_mlp.1.weight"] = torch.randn(4 * H, 256, generator=g) / 16; sd["rnn.time_mlp.1.bias"] = torch.zeros(4 * H)
+    sd["rnn.norm.weight"] = 1 + 0.1 * torch.randn(2 * H, generator=g); sd["rnn.norm.bias"] = 0.1 * torch.randn(2 * H, generator=g)
+    sd["fc.weight"] = torch.randn(C, 2 * H, generator=g) / np.sqrt(2 * H); sd["fc.bias"] = 0.1 * torch.randn(C, generator=g)
+    return {k_: v.numpy() for k_, v in sd.items()}
+
+
+def test_eicu_width_training_path(dev):
+    """H = 256 (8 unit blocks, the full-width kernels: 160 KiB LDS, per-sequence FiLM head, 8-wave BPTT sweep) at a
+    ragged batch: the saving forward equals the inference forward bit for bit, and the parameter gradients agree
+    with the fp32 oracle's BPTT within the bf16 bound."""
+    H, L, C, B = 256, 20, 14, 37
+    sd = _random_eicu_state(H, C, 5)
+    den = den_kernels(sd, dev)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, C, L)).astype(np.float32)
+    x[:, 4:] = np.where(rng.random((B, 10, L)) > 0.5, 0.0, -69.07755279).astype(np.float32)
+    t = rng.integers(0, 1000, B)
+    gy = (rng.standard_normal((B, C, L)) / (B * L)).astype(np.float32)
+    film = den.time_film(cu(t, dev))
+    y_inf = den.forward(cu(x, dev), film=film).cpu().numpy()
+    y_tr = den.forward_train(cu(x, dev), film).cpu().numpy()
+    np.testing.assert_array_equal(y_tr, y_inf)
+    o32 = orc.Denoiser(sd)
+    assert np.abs(y_tr - orc.Denoiser(sd, bf16=True).forward(x, t)).max() < 2e-2
+    g_layer, g_misc, g_film = den.backward(cu(gy, dev), film)
+    _, _, ref = o32.backward(x, t, gy)
+    for key, got in list(zip(den._lkeys, g_layer)) + list(g_misc.items()):
+        assert _rel(got.cpu().numpy(), ref[key]) < 3e-2, (key, _rel(got.cpu().numpy(), ref[key]))

@@ -208,6 +208,60 @@ __global__ __launch_bounds__(256) void td_pack_input_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// sampler: diffusion state -> layer-0 input fragments in one pass (= td_build_input_kernel followed by
+// td_pack_input_kernel, bit for bit).  The state is channel-major with l contiguous, the fragments want 32
+// sequences x 8 channels per 1 KiB: a (channels x 32 sequences x 16 positions) tile goes through LDS so that both
+// the reads (64 B runs along l) and the writes (1 KiB fragments) are coalesced.
+// ---------------------------------------------------------------------------------------------
+#define TD_SF_LT 16
+__global__ __launch_bounds__(256) void td_state_to_frags_kernel(td_diffusion_config c, int sumk, const float *__restrict__ z,
+                                                                const uint8_t *__restrict__ idx, char *__restrict__ dst, int B,
+                                                                int nbb, int kx0) {
+    extern __shared__ float tile[];   // [16 kx0][32][TD_SF_LT + 1]
+    const int L = c.seq_len, CP = 16 * kx0, C_io = c.n_num + sumk;
+    const int l0 = blockIdx.x * TD_SF_LT, bblk = blockIdx.y, tid = threadIdx.x;
+    const int RS = TD_SF_LT + 1;
+    for (int e = tid; e < (CP - C_io) * 32 * TD_SF_LT; e += 256) {   // channels past the denoiser width
+        const int ll = e % TD_SF_LT, bb = (e / TD_SF_LT) % 32, ch = C_io + e / (TD_SF_LT * 32);
+        tile[(ch * 32 + bb) * RS + ll] = 0.f;
+    }
+    for (int e = tid; e < c.n_num * 32 * TD_SF_LT; e += 256) {
+        const int ll = e % TD_SF_LT, bb = (e / TD_SF_LT) % 32, ch = e / (TD_SF_LT * 32);
+        const int b = bblk * 32 + bb, l = l0 + ll;
+        tile[(ch * 32 + bb) * RS + ll] = (b < B && l < L) ? z[((size_t)b * c.n_num + ch) * L + l] : 0.f;
+    }
+    for (int e = tid; e < c.n_cat * 32 * TD_SF_LT; e += 256) {
+        const int ll = e % TD_SF_LT, bb = (e / TD_SF_LT) % 32, v = e / (TD_SF_LT * 32);
+        const int b = bblk * 32 + bb, l = l0 + ll;
+        const bool ok = b < B && l < L;
+        const int cur = ok ? idx[((size_t)b * c.n_cat + v) * L + l] : -1;
+        int off = c.n_num;
+        for (int w = 0; w < v; ++w) off += c.num_classes[w];
+        for (int k = 0; k < c.num_classes[v]; ++k)
+            tile[((off + k) * 32 + bb) * RS + ll] = !ok ? 0.f : (k == cur ? 0.f : TD_LOG_1E30);   // mixed_diffusion.py:44-51
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, m = lane & 31, hf = lane >> 5;
+    for (int ll = wave; ll < TD_SF_LT; ll += 4) {
+        const int l = l0 + ll;
+        if (l >= L) break;
+        for (int kx = 0; kx < kx0; ++kx) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = tile[((16 * kx + 8 * hf + j) * 32 + m) * RS + ll];
+                const __bf16 h = (__bf16)v;
+                hi[j] = h;
+                lo[j] = (__bf16)(v - (float)h);
+            }
+            char *o = dst + (((size_t)l * nbb + bblk) * (2 * kx0) + 2 * kx) * TD_FRAG_BYTES + lane * 16;
+            *(bf16x8 *)o = hi;
+            *(bf16x8 *)(o + TD_FRAG_BYTES) = lo;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // head: LayerNorm(D*H) -> FiLM -> fc -> (B, C_out, L)   (blocks.py:293-297, :340-341)
 //
 // One wave per (position, batch block of 32 sequences).  The last layer's fragments of a
@@ -378,7 +432,7 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
     const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
-    {
+    if (x) {   // x == nullptr: x0 already holds the layer-0 fragments (td_rnn_run_layers_state)
         size_t total = (size_t)L * nbb * g.kx0 * 64;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 8192) blocks = 8192;
@@ -422,6 +476,29 @@ int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float 
     for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
     *last_act = acts[cfg->layers - 1];
     return td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, stream);
+}
+
+// Sampler path: the layer-0 fragments come straight from the diffusion state (z, class ids).
+int td_rnn_run_layers_state(const td_rnn_config *cfg, const void *packed, const td_diffusion_config *dcfg, const float *z,
+                            const uint8_t *idx, int batch, int L, void *workspace, hipStream_t stream, const char **last_act) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    size_t x0_bytes, act_bytes;
+    td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
+    char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
+    int sumk = 0;
+    for (int v = 0; v < dcfg->n_cat; ++v) sumk += dcfg->num_classes[v];
+    TD_REQUIRE(dcfg->n_num + sumk == cfg->c_in && dcfg->seq_len == L, "diffusion state does not match the denoiser input");
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    const size_t shm = (size_t)16 * g.kx0 * 32 * (TD_SF_LT + 1) * sizeof(float);
+    hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), shm, stream, *dcfg, sumk, z, idx, x0,
+                       batch, nbb, g.kx0);
+    TD_LAUNCH_CHECK();
+    char *acts[16];
+    for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
+    *last_act = acts[cfg->layers - 1];
+    return td_rnn_run_layers_ex(cfg, packed, nullptr, batch, L, x0, acts, nullptr, stream);
 }
 
 template <int KT>

@@ -329,8 +329,9 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 if constexpr (o == 6) t[2] = __builtin_amdgcn_rcpf(t[2] + 1.0f);  // g = 1 - 2 t[2]
                 if constexpr (o == 7) t[3] = __builtin_amdgcn_rcpf(1.0f + t[3]);  // o
                 if constexpr (o == 8) {
-                    const float gg = 1.0f - 2.0f * t[2];
-                    const float cv = t[1] * td_unpark(state[ub][r]) + t[0] * gg;
+                    // explicit fma: every instantiation (inference / training) rounds the same way
+                    const float gg = __builtin_fmaf(-2.0f, t[2], 1.0f);
+                    const float cv = __builtin_fmaf(t[1], td_unpark(state[ub][r]), t[0] * gg);
                     state[ub][r] = td_park(cv);
                     t[4] = cv;
                     if constexpr (SAVE) {
@@ -339,17 +340,17 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 }
                 if constexpr (o == 9) t[5] = __builtin_amdgcn_exp2f(P2L2E * t[4]);
                 if constexpr (o == 10) t[5] = __builtin_amdgcn_rcpf(t[5] + 1.0f);
-                if constexpr (o == 11) hval = t[3] * (1.0f - 2.0f * t[5]);
+                if constexpr (o == 11) hval = t[3] * __builtin_fmaf(-2.0f, t[5], 1.0f);
             } else {
                 if constexpr (o == 0) t[0] = __builtin_amdgcn_exp2f(NL2E * a[0][r]);
                 if constexpr (o == 1) t[1] = __builtin_amdgcn_exp2f(NL2E * a[1][r]);
                 if constexpr (o == 2) t[0] = __builtin_amdgcn_rcpf(1.0f + t[0]);  // r
                 if constexpr (o == 3) t[1] = __builtin_amdgcn_rcpf(1.0f + t[1]);  // z
-                if constexpr (o == 4) t[2] = __builtin_amdgcn_exp2f(P2L2E * (a[2][r] + t[0] * a[3][r]));
+                if constexpr (o == 4) t[2] = __builtin_amdgcn_exp2f(P2L2E * __builtin_fmaf(t[0], a[3][r], a[2][r]));
                 if constexpr (o == 5) t[2] = __builtin_amdgcn_rcpf(t[2] + 1.0f);
                 if constexpr (o == 6) {
-                    const float ng = 1.0f - 2.0f * t[2];
-                    const float h = (1.0f - t[1]) * ng + t[1] * td_unpark(state[ub][r]);
+                    const float ng = __builtin_fmaf(-2.0f, t[2], 1.0f);
+                    const float h = __builtin_fmaf(t[1], td_unpark(state[ub][r]), (1.0f - t[1]) * ng);
                     state[ub][r] = td_park(h);
                     if constexpr (SAVE) {
                         sbuf[0][r & 3] = t[0]; sbuf[1][r & 3] = t[1]; sbuf[2][r & 3] = ng; sbuf[3][r & 3] = a[3][r]; sbuf[4][r & 3] = h;

@@ -1,5 +1,5 @@
 // The T-step reverse chain (mixed_diffusion.py:425-454, gaussian_diffusion.py:133-152) as a replayed
-// hipGraph: one captured step = {denoiser input, layer-0 packing, recurrent layers, head, reverse
+// hipGraph: one captured step = {denoiser input + layer-0 packing, recurrent layers, head, reverse
 // update, step counter decrement}; every kernel reads the step index from a device counter, so the
 // same executable graph is launched T times with no host round trip in between.
 #include "common.h"
@@ -8,6 +8,8 @@
 
 int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, void *workspace,
                       hipStream_t stream, const char **last_act);
+int td_rnn_run_layers_state(const td_rnn_config *cfg, const void *packed, const td_diffusion_config *dcfg, const float *z,
+                            const uint8_t *idx, int batch, int L, void *workspace, hipStream_t stream, const char **last_act);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
                 const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
@@ -99,14 +101,9 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
 
     auto enqueue_step = [&]() -> int {
         int r;
-        const float *den_in = z;
-        if (cfg->n_cat > 0) {
-            r = td_build_denoiser_input(cfg, batch, z, idx, x_in, stream);
-            if (r != TD_OK) return r;
-            den_in = x_in;
-        }
         const char *act = nullptr;
-        r = td_rnn_run_layers(rnn, packed, den_in, batch, L, rnn_ws, stream, &act);
+        // denoiser input (mixed_diffusion.py:439) and its layer-0 fragment packing in one pass
+        r = td_rnn_run_layers_state(rnn, packed, cfg, z, idx, batch, L, rnn_ws, stream, &act);
         if (r != TD_OK) return r;
         r = td_rnn_head(rnn, misc, act, film_table, T, counter, batch, L, mo, stream);
         if (r != TD_OK) return r;

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Achieved HBM GB/s of the fused diffusion kernels (q_sample, reverse update, loss + gradient, head) at the
+bench's batch, against MI355X's 8 TB/s: algorithmic bytes / HIP-event time.
+usage (GPU box): python3 tools/diffusion_bench.py [batch]   -> one JSON line"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import EICU, init_state  # noqa: E402
+from timediff_amd.ops import DenoiserKernels, DiffusionKernels  # noqa: E402
+from timediff_amd.schedule import make_tables  # noqa: E402
+
+HBM_PEAK = 8000.0  # GB/s
+
+
+def timed(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    dev = torch.device("cuda:0")
+    cols, L, T, H, N, D = EICU, 272, 1000, 256, 3, 2
+    n_num, n_cat, sumk = len(cols["num"]), len(cols["cat"]), sum(cols["K"])
+    C_io, C = n_num + sumk, n_num + n_cat
+    diff = DiffusionKernels(cols["num"], cols["cat"], cols["K"], L, T, make_tables(T, "cosine"), C, dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    data = torch.rand(B, C, L, device=dev, generator=g)
+    for c in cols["cat"]:
+        data[:, c] = (data[:, c] > 0.5).float()
+    t = torch.randint(0, T, (B,), device=dev, generator=g)
+    res = {}
+
+    def rec(name, secs, nbytes):
+        res[name] = dict(ms=secs * 1e3, algorithmic_bytes=nbytes, gbps=nbytes / secs / 1e9, frac_of_hbm_peak=nbytes / secs / 1e9 / HBM_PEAK)
+
+    # q_sample: data in, x_in + noise + two uint8 index tensors out
+    x_in, x0i, xti, noise = diff.q_sample(data, t, seed=3)
+    rec("td_q_sample_kernel", timed(lambda: diff.q_sample(data, t, seed=3)),
+        B * L * (4 * C + 4 * C_io + 4 * n_num + 2 * n_cat))
+    # loss + gradient: model_out + noise + indices in, gradient out
+    mo = torch.randn(B, C_io, L, device=dev, generator=g)
+    rec("td_mixed_loss_kernel", timed(lambda: diff.mixed_loss(mo, noise, x0i, xti, t, 0.8)),
+        B * L * (2 * 4 * C_io + 4 * n_num + 2 * n_cat))
+    # reverse update (Philox noise): model_out in, z in/out, idx in/out
+    z, idx = diff.prior(B, seed=5)
+    rec("td_reverse_step_kernel", timed(lambda: diff.reverse_step_(mo, z, idx, 500, seed=5)),
+        B * L * (4 * C_io + 2 * 4 * n_num + 2 * n_cat))
+    rec("td_build_input_kernel", timed(lambda: diff.build_input(z, idx)), B * L * (4 * n_num + n_cat + 4 * C_io))
+    # head: last layer's fragments in, (B, C_io, L) out  -- timed through a whole denoiser forward minus the layers is not
+    # separable here; the rocprof kernel stats of bench.py give its duration (profiles/README.md)
+    print(json.dumps(dict(batch=B, seq_len=L, hbm_peak_gbps=HBM_PEAK, kernels=res)))
+
+
+if __name__ == "__main__":
+    main()
