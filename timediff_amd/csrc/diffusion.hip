@@ -162,9 +162,17 @@ __global__ __launch_bounds__(256) void td_reverse_step_kernel(td_diffusion_confi
             z[zi] = mean + sigma * nz;                            // :422
         }
         int off = 0;
+        // q(x_t | x_{t-1}) in log space (:255-262) takes two values per class count: the current class or not
+        int lastK = -1;
+        float logK = 0.f, w_hit = 0.f, w_miss = 0.f;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
-            const float logK = logf((float)K);
+            if (K != lastK) {
+                lastK = K;
+                logK = logf((float)K);
+                w_hit = td_log_add_exp(0.f + la, l1ma - logK);
+                w_miss = td_log_add_exp(TD_LOG_1E30 + la, l1ma - logK);
+            }
             const float *zp = mo + ((size_t)b * C_io + c.n_num + off) * L + l;
             float logit[TD_KMAX];
             float m = -INFINITY;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void td_reverse_step_kernel(td_diffusion_confi
                 if (k < K) {
                     const float lx0 = logit[k] - lse;
                     const float ev = t == 0 ? lx0 : td_log_add_exp(lx0 + lca, l1mca - logK);   // :284-290
-                    const float w = td_log_add_exp((k == xt ? 0.f : TD_LOG_1E30) + la, l1ma - logK);  // :255-262
+                    const float w = k == xt ? w_hit : w_miss;
                     // the per-slice normaliser (:293) shifts all K values equally: argmax-invariant
                     const float val = td_gumbel(draw.uniform(off + k)) + (ev + w);
                     if (val > bv) { bv = val; best = k; }
@@ -245,9 +253,17 @@ __global__ __launch_bounds__(256) void td_mixed_loss_kernel(td_diffusion_config 
         const float s_prev = tb == 0 ? 1.0f : expf(lca);
         float term = 0.f, prior = 0.f;
         int off = 0;
+        // q(x_t | x_{t-1}) in log space (:255-262) takes two values per class count: the current class or not
+        int lastK = -1;
+        float logK = 0.f, w_hit = 0.f, w_miss = 0.f;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
-            const float logK = logf((float)K);
+            if (K != lastK) {
+                lastK = K;
+                logK = logf((float)K);
+                w_hit = td_log_add_exp(0.f + la, l1ma - logK);
+                w_miss = td_log_add_exp(TD_LOG_1E30 + la, l1ma - logK);
+            }
             const float *zp = mo + ((size_t)b * C_io + c.n_num + off) * L + l;
             const int x0 = x0_idx[((size_t)b * c.n_cat + v) * L + l], xt = xt_idx[((size_t)b * c.n_cat + v) * L + l];
             float lx0h[TD_KMAX], ut[TD_KMAX], um[TD_KMAX];

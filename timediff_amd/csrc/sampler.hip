@@ -1,7 +1,7 @@
 // The T-step reverse chain (mixed_diffusion.py:425-454, gaussian_diffusion.py:133-152) as a replayed
 // hipGraph: one captured step = {denoiser input + layer-0 packing, recurrent layers, head, reverse
 // update, step counter decrement}; every kernel reads the step index from a device counter, so the
-// same executable graph is launched T times with no host round trip in between.
+// same executable graph (8 steps) is replayed T / 8 times with no host round trip in between.
 #include "common.h"
 
 #include <string.h>
@@ -18,6 +18,8 @@ int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const floa
 
 __global__ void td_set_counter_kernel(int32_t *p, int32_t v) { p[0] = v; }
 __global__ void td_dec_counter_kernel(int32_t *p) { p[0] -= 1; }
+
+#define TD_STEPS_PER_GRAPH 8
 
 struct TdChainKey {
     td_rnn_config rnn;
@@ -115,6 +117,9 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
         return TD_OK;
     };
 
+    // One graph launch carries several steps: a launch costs the GPU an idle gap of the order of a millisecond
+    // (measured: 36.0 ms per step with one step per launch against 35.0 ms of kernel time).
+    const int steps_per_graph = T >= TD_STEPS_PER_GRAPH ? TD_STEPS_PER_GRAPH : 1;
     if (use_graph) {
         // The instantiated step graph is kept for the next call with identical arguments; a stale one
         // is released only after the stream it ran on has drained.
@@ -128,7 +133,7 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
             td_sample_chain_release();
             hipGraph_t graph = nullptr;
             TD_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_step();
+            for (int k = 0; k < steps_per_graph && rc == TD_OK; ++k) rc = enqueue_step();
             hipError_t e = hipStreamEndCapture(stream, &graph);
             if (rc != TD_OK) {
                 if (graph) (void)hipGraphDestroy(graph);
@@ -144,7 +149,13 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
             g_chain.key = key;
             g_chain.valid = true;
         }
-        for (int s = 0; s < T; ++s) TD_HIP(hipGraphLaunch(g_chain.exec, stream));
+        // every step reads its index from the device counter, so T steps = T / steps_per_graph replays of the
+        // captured block + the remainder enqueued directly
+        for (int s = 0; s < T / steps_per_graph; ++s) TD_HIP(hipGraphLaunch(g_chain.exec, stream));
+        for (int s = 0; s < T % steps_per_graph; ++s) {
+            rc = enqueue_step();
+            if (rc != TD_OK) return rc;
+        }
     } else {
         for (int s = 0; s < T; ++s) {
             rc = enqueue_step();
