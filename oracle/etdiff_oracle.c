@@ -189,12 +189,20 @@ static void rnn_dir(const OrRnnCfg *c, const float *w_ih, const float *w_hh, con
     float *wih_r = NULL, *whh_r = NULL;
     if (emul) {
         /* layer 0's input projection stays ~fp32 on the GPU (split-bf16 x3), everything else bf16 */
+        /* the GPU rounds the weights after folding in the factor its exp2-based gate math needs:
+         * -log2(e) for the sigmoid gates, 2 log2(e) for the tanh gate (LSTM g, GRU n) */
         whh_r = (float *)malloc(sizeof(float) * G * H * H);
-        for (int i = 0; i < G * H * H; ++i) whh_r[i] = bf16_round(w_hh[i]);
+        for (int i = 0; i < G * H * H; ++i) {
+            const float sc = (i / (H * H)) == 2 ? 2.8853900817779268f : -1.4426950408889634f;
+            whh_r[i] = bf16_round(w_hh[i] * sc) / sc;
+        }
         w_hh = whh_r;
         if (layer > 0) {
             wih_r = (float *)malloc(sizeof(float) * G * H * In);
-            for (int i = 0; i < G * H * In; ++i) wih_r[i] = bf16_round(w_ih[i]);
+            for (int i = 0; i < G * H * In; ++i) {
+                const float sc = (i / (H * In)) == 2 ? 2.8853900817779268f : -1.4426950408889634f;
+                wih_r[i] = bf16_round(w_ih[i] * sc) / sc;
+            }
             w_ih = wih_r;
         }
     }

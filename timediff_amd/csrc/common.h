@@ -39,6 +39,11 @@ static inline int td_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- device math -----------------------------------------------------------------------------
 #define TD_LOG_1E30 (-69.07755279f)  // log(clamp(one_hot, 1e-30)), reference mixed_diffusion.py:50
 
+// factors folded into the packed recurrent weights (td_pack_weights_kernel) so that the layer kernel's gate math
+// starts at exp2: -log2(e) for the sigmoid gates, 2 log2(e) for the tanh gate
+#define TD_GATE_SCALE_SIGMOID (-1.4426950408889634f)
+#define TD_GATE_SCALE_TANH (2.8853900817779268f)
+
 // v_exp_f32 / v_rcp_f32 (1 ulp) forms: these run 5x per hidden unit per time step
 __device__ __forceinline__ float td_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));

@@ -45,7 +45,7 @@ __global__ void td_pack_weights_kernel(TdPackParams p) {
         if (f < p.nf) {
             const int u = f / p.fu, rem0 = f % p.fu;
             const int unit = 32 * u + r;
-            int g, part = 0;
+            int g = 0, part = 0;
             bool lo = false;
             float w = 0.f;
             if (rem0 < 4) {  // bias k-step: column k = 0 carries bf16(b), k = 1 the remainder
@@ -80,6 +80,11 @@ __global__ void td_pack_weights_kernel(TdPackParams p) {
                 const int kk = 16 * ks + 8 * (j >> 2) + 4 * hf + (j & 3);
                 if (unit < p.H && kk < p.H) w = p.w_ih[(size_t)(g * p.H + unit) * p.In + din * p.H + kk];
             }
+            // Gate pre-activations leave the MFMA already multiplied by the factor their nonlinearity's exp2 needs:
+            // sigmoid(a) = 1 / (1 + 2^(-log2(e) a)), tanh(a) = 1 - 2 / (2^(2 log2(e) a) + 1).  Folding the factor into
+            // the weights and biases before the bf16 rounding saves a multiply per gate value in the layer kernel.
+            const bool tanh_gate = (rem0 < 4) ? (p.gru ? rem0 >= 2 : rem0 == 2) : g == 2;
+            w *= tanh_gate ? TD_GATE_SCALE_TANH : TD_GATE_SCALE_SIGMOID;
             if (lo) {
                 const __bf16 hi = (__bf16)w;
                 val = w - (float)hi;

@@ -315,15 +315,16 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         auto gate_op = [&](auto ubc, auto qc) {
             constexpr int ub = decltype(ubc)::value, q = decltype(qc)::value;
             constexpr int pair = q / (2 * NOPS), w = q % (2 * NOPS), o = w / 2, r = 2 * pair + (w & 1);
-            constexpr float NL2E = -1.4426950408889634f, P2L2E = 2.8853900817779268f;
+            constexpr float P2L2E = TD_GATE_SCALE_TANH;
             f32x16(&a)[4] = acc[ub & 1];
             float(&t)[6] = T0[r & 1];
             float hval = 0.f;
             if constexpr (!GRU) {
-                if constexpr (o == 0) t[0] = __builtin_amdgcn_exp2f(NL2E * a[0][r]);
-                if constexpr (o == 1) t[1] = __builtin_amdgcn_exp2f(NL2E * a[1][r]);
-                if constexpr (o == 2) t[2] = __builtin_amdgcn_exp2f(P2L2E * a[2][r]);
-                if constexpr (o == 3) t[3] = __builtin_amdgcn_exp2f(NL2E * a[3][r]);
+                // the accumulators arrive pre-multiplied by -log2(e) (i, f, o) / 2 log2(e) (g): td_pack_weights_kernel
+                if constexpr (o == 0) t[0] = __builtin_amdgcn_exp2f(a[0][r]);
+                if constexpr (o == 1) t[1] = __builtin_amdgcn_exp2f(a[1][r]);
+                if constexpr (o == 2) t[2] = __builtin_amdgcn_exp2f(a[2][r]);
+                if constexpr (o == 3) t[3] = __builtin_amdgcn_exp2f(a[3][r]);
                 if constexpr (o == 4) t[0] = __builtin_amdgcn_rcpf(1.0f + t[0]);  // i
                 if constexpr (o == 5) t[1] = __builtin_amdgcn_rcpf(1.0f + t[1]);  // f
                 if constexpr (o == 6) t[2] = __builtin_amdgcn_rcpf(t[2] + 1.0f);  // g = 1 - 2 t[2]
@@ -342,18 +343,19 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 if constexpr (o == 10) t[5] = __builtin_amdgcn_rcpf(t[5] + 1.0f);
                 if constexpr (o == 11) hval = t[3] * __builtin_fmaf(-2.0f, t[5], 1.0f);
             } else {
-                if constexpr (o == 0) t[0] = __builtin_amdgcn_exp2f(NL2E * a[0][r]);
-                if constexpr (o == 1) t[1] = __builtin_amdgcn_exp2f(NL2E * a[1][r]);
+                // pre-multiplied accumulators: -log2(e) (r, z), 2 log2(e) (both halves of n)
+                if constexpr (o == 0) t[0] = __builtin_amdgcn_exp2f(a[0][r]);
+                if constexpr (o == 1) t[1] = __builtin_amdgcn_exp2f(a[1][r]);
                 if constexpr (o == 2) t[0] = __builtin_amdgcn_rcpf(1.0f + t[0]);  // r
                 if constexpr (o == 3) t[1] = __builtin_amdgcn_rcpf(1.0f + t[1]);  // z
-                if constexpr (o == 4) t[2] = __builtin_amdgcn_exp2f(P2L2E * __builtin_fmaf(t[0], a[3][r], a[2][r]));
+                if constexpr (o == 4) t[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[0], a[3][r], a[2][r]));
                 if constexpr (o == 5) t[2] = __builtin_amdgcn_rcpf(t[2] + 1.0f);
                 if constexpr (o == 6) {
                     const float ng = __builtin_fmaf(-2.0f, t[2], 1.0f);
                     const float h = __builtin_fmaf(t[1], td_unpark(state[ub][r]), (1.0f - t[1]) * ng);
                     state[ub][r] = td_park(h);
                     if constexpr (SAVE) {
-                        sbuf[0][r & 3] = t[0]; sbuf[1][r & 3] = t[1]; sbuf[2][r & 3] = ng; sbuf[3][r & 3] = a[3][r]; sbuf[4][r & 3] = h;
+                        sbuf[0][r & 3] = t[0]; sbuf[1][r & 3] = t[1]; sbuf[2][r & 3] = ng; sbuf[3][r & 3] = a[3][r] * (1.0f / P2L2E); sbuf[4][r & 3] = h;
                     }
                     hval = h;
                 }
