@@ -230,7 +230,7 @@ def main():
                         traffic=traffic, traffic_unit="bytes per launch (PMC)", launches_timed=cnt.value,
                         avg_launch_ms=avg_s * 1e3, flops_per_launch=flops_launch)
         base = None
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only: the other ranks would wait on it
             base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()})
         train = None
         if world == 1 and not args.no_train_probe:

@@ -18,6 +18,7 @@ import copy
 import ctypes as C
 import logging
 import os
+import sys
 import timeit
 
 import torch
@@ -97,7 +98,7 @@ class ETDiff(nn.Module):
         self._device = torch.device("cuda", local_rank)
         if self.world > 1 and not torch.distributed.is_initialized():
             torch.distributed.init_process_group("nccl", device_id=self._device)
-        print(f"*** Using device: {self._device} ***")
+        print(f"*** Using device: {self._device} ***", file=sys.stderr)
 
         self.timer = timeit.default_timer
         self.wandb = wandb
