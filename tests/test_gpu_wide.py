@@ -1,0 +1,96 @@
+"""GPU parity of the wide-hidden kernels (256 < H <= 1024: BASELINE.json configs[3] "wider hidden size" and
+configs[4] "wide-hidden BRNN"; timediff_amd/csrc/rnn_wide.hip) against the CPU oracle.
+
+The reference holds no vectors at these widths and a golden fixture would carry > 10 MB of weights, so the
+oracle here is the same C restatement that tests/test_oracle_golden.py pins against the reference at H <= 92
+(it is generic in H); weights are torch-default-initialised from a seed.  Tolerances as in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from test_gpu_parity import BF16_EMUL_ATOL, _rel, cu, den_kernels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def random_state(H, C, layers, dirs, gru, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / np.sqrt(H)
+    G = 3 if gru else 4
+    sd = {}
+    for l in range(layers):
+        for sfx in ("", "_reverse")[:dirs]:
+            In = C if l == 0 else dirs * H
+            sd[f"rnn.rnn.weight_ih_l{l}{sfx}"] = (torch.rand(G * H, In, generator=g) * 2 - 1) * k
+            sd[f"rnn.rnn.weight_hh_l{l}{sfx}"] = (torch.rand(G * H, H, generator=g) * 2 - 1) * k
+            sd[f"rnn.rnn.bias_ih_l{l}{sfx}"] = (torch.rand(G * H, generator=g) * 2 - 1) * k
+            sd[f"rnn.rnn.bias_hh_l{l}{sfx}"] = (torch.rand(G * H, generator=g) * 2 - 1) * k
+    DH = dirs * H
+    sd["time_emb.1.weight"] = torch.randn(256, 64, generator=g) / 8; sd["time_emb.1.bias"] = torch.zeros(256)
+    sd["time_emb.3.weight"] = torch.randn(256, 256, generator=g) / 16; sd["time_emb.3.bias"] = torch.zeros(256)
+    sd["rnn.time_mlp.1.weight"] = torch.randn(2 * DH, 256, generator=g) / 16; sd["rnn.time_mlp.1.bias"] = torch.zeros(2 * DH)
+    sd["rnn.norm.weight"] = 1 + 0.1 * torch.randn(DH, generator=g); sd["rnn.norm.bias"] = 0.1 * torch.randn(DH, generator=g)
+    sd["fc.weight"] = torch.randn(C, DH, generator=g) / np.sqrt(DH); sd["fc.bias"] = 0.1 * torch.randn(C, generator=g)
+    return {k_: v.numpy() for k_, v in sd.items()}
+
+
+def _inputs(B, C, L, n_num, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, C, L)).astype(np.float32)
+    x[:, n_num:] = np.where(rng.random((B, C - n_num, L)) > 0.5, 0.0, -69.07755279).astype(np.float32)
+    return x, rng.integers(0, 1000, B), rng
+
+
+# (H, layers, dirs, gru, C, n_num, B, L): HiRID-shaped (C_io = 9) and eICU-shaped (14) channel maps
+WIDE = [
+    (512, 3, 2, 0, 14, 4, 37, 9),     # 16 unit blocks, ragged batch
+    (320, 2, 2, 1, 9, 7, 33, 7),      # GRU, 10 blocks padded to 12
+    (1024, 2, 2, 0, 9, 7, 32, 5),     # 32 blocks: 128 KiB of LDS for h
+    (768, 2, 1, 0, 23, 7, 5, 6),      # unidirectional, 24 blocks, two layer-0 input k-steps
+    (400, 2, 1, 1, 14, 4, 64, 4),     # GRU padded 13 -> 16 blocks
+]
+
+
+@pytest.mark.parametrize("H,layers,dirs,gru,C,n_num,B,L", WIDE)
+def test_wide_denoiser_forward(H, layers, dirs, gru, C, n_num, B, L, dev):
+    sd = random_state(H, C, layers, dirs, gru, seed=H + layers)
+    den = den_kernels(sd, dev)
+    x, t, _ = _inputs(B, C, L, n_num, seed=H)
+    y, hidden = den.forward(cu(x, dev), cu(t, dev), want_hidden=True)
+    y, hidden = y.cpu().numpy(), hidden.cpu().numpy()
+    y16, h16 = orc.Denoiser(sd, bf16=True).forward(x, t, want_hidden=True)
+    assert np.isfinite(y).all()
+    assert np.abs(hidden - h16).max() < BF16_EMUL_ATOL, np.abs(hidden - h16).max()
+    assert np.abs(y - y16).max() < 2e-2, np.abs(y - y16).max()
+    y32 = orc.Denoiser(sd).forward(x, t)
+    assert np.abs(y - y32).max() < 6e-2, np.abs(y - y32).max()
+    # one shared FiLM row (the sampler's call: every sequence at the same step)
+    t1 = np.full(B, 321)
+    y1 = den.forward(cu(x, dev), film=den.time_film(cu(t1[:1], dev))).cpu().numpy()
+    assert np.abs(y1 - orc.Denoiser(sd, bf16=True).forward(x, t1)).max() < 2e-2
+
+
+def test_wide_sample_chain_matches_stepwise(dev):
+    """HiRID-shaped wide sampler (C_io = 9, H = 512): the captured-graph chain equals the eager step-by-step chain
+    bit for bit, and the decoded samples are in range."""
+    from timediff_amd.ops import DiffusionKernels, SamplerKernels
+    H, L, T, B = 512, 12, 8, 40
+    num, cat, K = [0, 1, 2, 3, 4, 5, 6], [7], [2]
+    sd = random_state(H, 9, 3, 2, 0, seed=11)
+    den = den_kernels(sd, dev)
+    tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
+    diff = DiffusionKernels(num, cat, K, L, T, tables, 8, dev)
+    sampler = SamplerKernels(den, diff)
+    a = sampler.sample(B, seed=5, patient0=100).cpu().numpy()
+    b = sampler.sample(B, seed=5, patient0=100, use_graph=False).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (B, 8, L) and np.isfinite(a).all()
+    assert ((a[:, cat] == 0) | (a[:, cat] == 1)).all() and a[:, num].min() >= 0 and a[:, num].max() <= 1

@@ -425,6 +425,10 @@ int td_launch_layer_infer(int gru, int nu, const TdLayerParams &p, bool layer0, 
     return td_launch_layer_dispatch(gru, 0, nu, p, layer0, kxsel, stream);
 }
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
+// rnn_wide.hip: hidden sizes above 256
+int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream);
+int td_rnn_head_wide(const td_rnn_config *cfg, const TdRnnGeom &g, const float *const *misc, const char *act, const float *film,
+                     int film_rows, const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
 
 int td_profile_begin(void *stream);
 void td_profile_end(int slot, void *stream);
@@ -456,7 +460,11 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
         p.save = saves ? saves[l] : nullptr;
         p.save_dir_stride = (size_t)L * nbb * g.nu * 5 * 1024;
         const int kxsel = l == 0 ? g.kx0 : g.dirs;
-        if (saves) {
+        if (g.nu > 8) {
+            const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
+            rc = td_launch_layer_wide(cfg->gru, saves ? 1 : 0, g.nu, p, l == 0, g.kx0, stream);
+            td_profile_end(slot, stream);
+        } else if (saves) {
             rc = td_launch_layer_save(cfg->gru, g.nu, p, l == 0, kxsel, stream);
         } else {
             const int slot = l > 0 ? td_profile_begin(stream) : -1;
@@ -521,6 +529,7 @@ int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *
     TdRnnGeom g;
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
+    if (g.dirs * g.kh > 32) return td_rnn_head_wide(cfg, g, misc, act, film, film_rows, film_row, batch, L, y, stream);
     TdHeadParams p;
     p.act = act;
     p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.fc_b = misc[TD_FC_B];

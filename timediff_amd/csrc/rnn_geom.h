@@ -23,7 +23,7 @@ static inline int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
     TD_REQUIRE(cfg->time_dim >= 1 && cfg->time_dim <= 1024, "bad time_dim %d", cfg->time_dim);
     int nu = td_round_nu(cfg->hidden);
     if (nu < 0) {
-        td_set_error("hidden = %d > 256 is not supported by this build", cfg->hidden);
+        td_set_error("hidden = %d > 1024 is not supported by this build", cfg->hidden);
         return TD_ERR_UNSUPPORTED;
     }
     int kx0 = (cfg->c_in + 15) / 16;

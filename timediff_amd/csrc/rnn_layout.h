@@ -32,8 +32,10 @@ struct TdLayerGeom {
 
 static inline int td_round_nu(int hidden) {
     int nu = (hidden + 31) / 32;
-    static const int ok[] = {1, 2, 3, 4, 6, 8};
-    for (int i = 0; i < 6; ++i)
+    // up to 8 blocks (H <= 256): rnn_layer.h, one wave holds a batch block's whole state; 12..32 blocks
+    // (H <= 1024): rnn_wide.hip, the four waves of a workgroup split the unit blocks
+    static const int ok[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int i = 0; i < 10; ++i)
         if (nu <= ok[i]) return ok[i];
     return -1;
 }

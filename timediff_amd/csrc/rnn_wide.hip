@@ -1,0 +1,338 @@
+// Wide hidden sizes (256 < H <= 1024: BASELINE.json configs[3], [4]) of the recurrent layer and the head.
+//
+// Above H = 256 the state of 32 sequences (cell state fp32 + h as B fragments) no longer fits one wave's
+// registers, so the decomposition of rnn_layer.h turns by 90 degrees: a workgroup (4 waves, one per SIMD)
+// owns ONE batch block of 32 sequences for all L steps and splits the hidden units: wave w owns the NUW
+// 32-unit blocks w*NUW .. w*NUW+NUW-1 (their cell state stays in its registers).  h_{t-1} of all units is the
+// B operand of every wave's recurrent k-steps and lives in LDS (double buffered, KH KiB each: one barrier per
+// step).  The weight fragments are the same packed stream rnn_layer.h reads ([unit block][bias | W_hh k-steps |
+// W_ih k-steps][gate], td_pack_weights_kernel); each wave streams its own blocks' fragments L2 -> registers
+// through a two-chunk software pipeline (a chunk = 4 k-steps = 4*NG fragments).  The layer's input fragments
+// are read from L2/HBM as B operands with the chunk that uses them.
+//
+// Gate math: the same instruction sequence as rnn_layer.h's gate_op (the accumulators arrive pre-multiplied
+// by the exp2 factors), so the oracle's bf16 emulation covers both kernels.
+#include "rnn_geom.h"
+#include "rnn_params.h"
+
+template <int N, class F>
+__device__ __forceinline__ void tdw_static_for(F &&f) {
+    if constexpr (N > 0) {
+        tdw_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int NUW, bool L0, bool GRU, bool SAVE>
+__global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
+    constexpr int NG = GRU ? 3 : 4, NU = 4 * NUW, KH = 2 * NU, CH = 4 * NG;   // CH: weight fragments per chunk
+    extern __shared__ __attribute__((aligned(16))) char hlds[];                 // [2][KH] fragments
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = p.dirs == 2 ? (blockIdx.x & 1) : 0;
+    const int bb = p.dirs == 2 ? (blockIdx.x >> 1) : blockIdx.x;
+    const int KXF = L0 ? 0 : p.in_frags;                 // input k-steps above the first layer (= dirs * KH)
+    const int XFR0 = L0 ? 2 * kx0 : 0;                   // first layer: hi + lo fragments
+    const int FU = 4 + (KH + (L0 ? XFR0 : KXF)) * NG;    // weight fragments per unit block
+    const int NCH = (KH + KXF) / 4;                      // pipelined chunks per unit block (KH, KXF: multiples of 8)
+
+    for (int i = tid; i < KH * 64; i += 256) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0 (buffer 0)
+    __syncthreads();
+
+    float state[NUW][16];   // LSTM: cell state; GRU: hidden state (fp32)
+#pragma unroll
+    for (int i = 0; i < NUW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) state[i][r] = 0.f;
+    bf16x8 ones = {};
+    if (lane < 32) { ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f; }
+    const bf16x8 *wdir = (const bf16x8 *)(p.wpacked + (size_t)dir * p.dir_stride) + lane;
+
+    for (int s = 0; s < p.L; ++s) {
+        const int l = dir ? p.L - 1 - s : s;
+        const bf16x8 *hcur = (const bf16x8 *)(hlds + (size_t)(s & 1) * KH * TD_FRAG_BYTES) + lane;
+        bf16x8 *hnext = (bf16x8 *)(hlds + (size_t)((s + 1) & 1) * KH * TD_FRAG_BYTES) + lane;
+        const bf16x8 *xp = (const bf16x8 *)(p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES) + lane;
+        bf16x8 *op = (bf16x8 *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES) + lane;
+
+        tdw_static_for<NUW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = wave * NUW + i;
+            const bf16x8 *wa = wdir + (size_t)u * FU * 64;
+            f32x16 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+            // chunk c of the stream after the bias fragments: weight fragments + the B operands they meet
+            bf16x8 A0[CH], A1[CH], B0[4], B1[4];
+            auto load = [&](int c, bf16x8(&A)[CH], bf16x8(&B)[4]) {
+                const bf16x8 *wp = wa + (size_t)(4 + c * CH) * 64;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) A[j] = wp[j * 64];
+                if (4 * c < KH) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) B[k] = hcur[(4 * c + k) * 64];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) B[k] = xp[(4 * c - KH + k) * 64];
+                }
+            };
+            auto compute = [&](int c, bf16x8(&A)[CH], bf16x8(&B)[4]) {
+                const bool rec = 4 * c < KH;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (GRU && g == 2) {
+                            // n gate: the recurrent half accumulates apart (it is multiplied by r)
+                            if (rec) acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[3], 0, 0, 0);
+                            else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[2], 0, 0, 0);
+                        } else {
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[g], 0, 0, 0);
+                        }
+                    }
+            };
+            load(0, A0, B0);
+            // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden), hi + lo columns against ones
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[f * 64], ones, acc[f], 0, 0, 0);
+            for (int c = 0; c < NCH; c += 2) {   // NCH is even
+                load(c + 1, A1, B1);
+                compute(c, A0, B0);
+                if (c + 2 < NCH) load(c + 2, A0, B0);
+                compute(c + 1, A1, B1);
+            }
+            if constexpr (L0) {
+                // first layer: W = Whi + Wlo, x = xhi + xlo in bf16, the three leading products (rnn_layer.h)
+                const bf16x8 *wp = wa + (size_t)(4 + KH * NG) * 64;
+                for (int kx = 0; kx < kx0; ++kx) {
+                    const bf16x8 xhi = xp[(2 * kx) * 64], xlo = xp[(2 * kx + 1) * 64];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const bf16x8 whi = wp[(size_t)(2 * (kx * NG + g)) * 64], wlo = wp[(size_t)(2 * (kx * NG + g) + 1) * 64];
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi, acc[g], 0, 0, 0);
+                    }
+                }
+            }
+
+            // gates (row r of the accumulator = unit 32u + (r&3) + 8(r>>2) + 4hf)
+            constexpr float P2L2E = TD_GATE_SCALE_TANH;
+            float hv[16];
+            float sv[5][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (!GRU) {
+                    const float e0 = __builtin_amdgcn_exp2f(acc[0][r]), e1 = __builtin_amdgcn_exp2f(acc[1][r]);
+                    const float e2 = __builtin_amdgcn_exp2f(acc[2][r]), e3 = __builtin_amdgcn_exp2f(acc[3][r]);
+                    const float ig = __builtin_amdgcn_rcpf(1.0f + e0), fg = __builtin_amdgcn_rcpf(1.0f + e1);
+                    const float t2 = __builtin_amdgcn_rcpf(e2 + 1.0f), og = __builtin_amdgcn_rcpf(1.0f + e3);
+                    const float gg = __builtin_fmaf(-2.0f, t2, 1.0f);
+                    const float cv = __builtin_fmaf(fg, state[i][r], ig * gg);
+                    state[i][r] = cv;
+                    float t5 = __builtin_amdgcn_exp2f(P2L2E * cv);
+                    t5 = __builtin_amdgcn_rcpf(t5 + 1.0f);
+                    hv[r] = og * __builtin_fmaf(-2.0f, t5, 1.0f);
+                    if constexpr (SAVE) { sv[0][r] = ig; sv[1][r] = fg; sv[2][r] = gg; sv[3][r] = og; sv[4][r] = cv; }
+                } else {
+                    const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
+                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
+                    float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[3][r], acc[2][r]));
+                    t2 = __builtin_amdgcn_rcpf(t2 + 1.0f);
+                    const float ng = __builtin_fmaf(-2.0f, t2, 1.0f);
+                    const float h = __builtin_fmaf(zg, state[i][r], (1.0f - zg) * ng);
+                    state[i][r] = h;
+                    hv[r] = h;
+                    if constexpr (SAVE) { sv[0][r] = rg; sv[1][r] = zg; sv[2][r] = ng; sv[3][r] = acc[3][r] * (1.0f / P2L2E); sv[4][r] = h; }
+                }
+            }
+            bf16x8 h0, h1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { h0[j] = (__bf16)hv[j]; h1[j] = (__bf16)hv[8 + j]; }
+            // the other buffer was last read in step s - 1, which every wave has left (barrier below)
+            hnext[(2 * u) * 64] = h0;
+            hnext[(2 * u + 1) * 64] = h1;
+            __builtin_nontemporal_store(h0, op + (2 * u) * 64);
+            __builtin_nontemporal_store(h1, op + (2 * u + 1) * 64);
+            if constexpr (SAVE) {
+                float *svb = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bb) * NU + u) * 5) * 1024 + lane * 16;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(f32x4 *)(svb + k * 1024 + 4 * q) = f32x4{sv[k][4 * q], sv[k][4 * q + 1], sv[k][4 * q + 2], sv[k][4 * q + 3]};
+            }
+        });
+        __syncthreads();   // h_t complete in LDS; every wave is done with h_{t-1}
+    }
+}
+
+template <int NUW, bool L0, bool GRU, bool SAVE>
+static int tdw_launch(const TdLayerParams &p, int kx0, hipStream_t stream) {
+    const size_t shm = (size_t)2 * (8 * NUW) * TD_FRAG_BYTES;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>), dim3(p.nbb * p.dirs), dim3(256), shm, stream, p, kx0);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+template <int NUW>
+static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
+    if (layer0) {
+        if (!gru) return save ? tdw_launch<NUW, true, false, true>(p, kx0, stream) : tdw_launch<NUW, true, false, false>(p, kx0, stream);
+        return save ? tdw_launch<NUW, true, true, true>(p, kx0, stream) : tdw_launch<NUW, true, true, false>(p, kx0, stream);
+    }
+    if (!gru) return save ? tdw_launch<NUW, false, false, true>(p, kx0, stream) : tdw_launch<NUW, false, false, false>(p, kx0, stream);
+    return save ? tdw_launch<NUW, false, true, true>(p, kx0, stream) : tdw_launch<NUW, false, true, false>(p, kx0, stream);
+}
+
+// nu: padded 32-unit blocks (12, 16, 24 or 32); kx0: layer-0 input k-steps
+int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
+    if (!layer0 && p.in_frags != p.dirs * 2 * nu) {
+        td_set_error("wide recurrent layer: %d input fragments, expected %d", p.in_frags, p.dirs * 2 * nu);
+        return TD_ERR_INVALID;
+    }
+    switch (nu) {
+        case 12: return tdw_dispatch<3>(gru, save, p, layer0, kx0, stream);
+        case 16: return tdw_dispatch<4>(gru, save, p, layer0, kx0, stream);
+        case 24: return tdw_dispatch<6>(gru, save, p, layer0, kx0, stream);
+        case 32: return tdw_dispatch<8>(gru, save, p, layer0, kx0, stream);
+    }
+    td_set_error("unsupported hidden block count %d", nu);
+    return TD_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// head for wide layers: LayerNorm(D*H) -> FiLM -> fc -> (B, C_out, L)   (blocks.py:293-297, :340-341)
+// Same arithmetic as td_head_kernel (rnn.hip), but a position's fragments (up to 128 KiB per batch block) do not fit
+// one wave's registers: three passes over them (mean, variance, projection; the second and third hit L2), and the
+// fc A fragments are built from the fp32 weights on the fly (256 KiB at D*H = 2048: L2-resident, too large for LDS
+// next to the per-feature vectors).
+// ---------------------------------------------------------------------------------------------
+struct TdHeadWideParams {
+    const char *act;
+    const float *ln_w, *ln_b, *fc_w, *fc_b, *film;
+    const int32_t *film_row;
+    float *y;
+    int film_rows, B, L, nbb, H, kh, dirs, c_out, per_seq;
+};
+
+__global__ __launch_bounds__(256) void td_head_wide_kernel(TdHeadWideParams p) {
+    extern __shared__ __attribute__((aligned(16))) float hv[];   // three [KT*16] vectors in fragment order (k = 8 hf + j)
+    const int KT = p.dirs * p.kh, DH = p.dirs * p.H;
+    float *v_a = hv, *v_b = v_a + KT * 16, *v_msk = v_b + KT * 16;
+    const float *film0 = p.film + (size_t)(p.film_row ? p.film_row[0] : 0) * 2 * DH;
+    for (int idx = threadIdx.x; idx < KT * 16; idx += 256) {
+        const int ks = idx / 16, hf = (idx % 16) / 8, j = idx % 8;
+        const int d = ks / p.kh, unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+        const bool ok = unit < p.H;
+        const int feat = d * p.H + (ok ? unit : 0);
+        const float lw = ok ? p.ln_w[feat] : 0.f, lb = ok ? p.ln_b[feat] : 0.f;
+        if (p.per_seq) {
+            v_a[idx] = lw; v_b[idx] = lb;
+        } else {
+            const float sc = ok ? film0[feat] + 1.0f : 0.f, sh = ok ? film0[DH + feat] : 0.f;
+            v_a[idx] = lw * sc; v_b[idx] = lb * sc + sh;
+        }
+        v_msk[idx] = ok ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
+    const size_t ntask = (size_t)p.L * p.nbb;
+    for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
+        const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
+        const int b = bblk * 32 + m;
+        const float *filmb = p.film + (size_t)(b < p.B ? b : 0) * 2 * DH;
+        const bf16x8 *fp = (const bf16x8 *)(p.act + task * KT * TD_FRAG_BYTES) + lane;
+        const float *va = v_a + hf * 8, *vb = v_b + hf * 8, *vm = v_msk + hf * 8;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)v[j];   // padded units hold exact zeros
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum / (float)DH;
+        float sq = 0.f;
+#pragma unroll 8
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = ((float)v[j] - mu) * vm[ks * 16 + j];
+                sq = fmaf(dlt, dlt, sq);
+            }
+        }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // A fragment of fc_w: lane (channel c = lane & 31, hf) holds units 16 ks + 8 (j >> 2) + 4 hf + (j & 3)
+        const bool cok = m < p.c_out;
+        const float *fcrow = p.fc_w + (size_t)(cok ? m : 0) * DH;
+#pragma unroll 2
+        for (int ks = 0; ks < KT; ++ks) {
+            const bf16x8 v = fp[ks * 64];
+            const int d = ks / p.kh, unit0 = 16 * (ks % p.kh) + 4 * hf;
+            bf16x8 yh, yl, wh, wl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int unit = unit0 + 8 * (j >> 2) + (j & 3);
+                const bool ok = unit < p.H;
+                float av = va[ks * 16 + j], bv = vb[ks * 16 + j];
+                if (p.per_seq) {
+                    const int feat = d * p.H + (ok ? unit : 0);
+                    const float sc = filmb[feat] + 1.0f, sh = filmb[DH + feat];
+                    bv = (bv * sc + sh) * vm[ks * 16 + j];
+                    av = av * sc;
+                }
+                const float yv = ((float)v[j] - mu) * rstd * av + bv;
+                const __bf16 h = (__bf16)yv;
+                yh[j] = h;
+                yl[j] = (__bf16)(yv - (float)h);
+                const float w = (cok && ok) ? fcrow[d * p.H + unit] : 0.f;
+                const __bf16 whj = (__bf16)w;
+                wh[j] = whj;
+                wl[j] = (__bf16)(w - (float)whj);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, yh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh, acc, 0, 0, 0);
+        }
+        if (b < p.B) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (c < p.c_out) p.y[((size_t)b * p.c_out + c) * p.L + l] = acc[r] + p.fc_b[c];
+            }
+        }
+    }
+}
+
+int td_rnn_head_wide(const td_rnn_config *cfg, const TdRnnGeom &g, const float *const *misc, const char *act, const float *film,
+                     int film_rows, const int32_t *film_row, int batch, int L, float *y, hipStream_t stream) {
+    TdHeadWideParams p;
+    p.act = act;
+    p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.fc_b = misc[TD_FC_B];
+    p.film = film; p.film_row = film_row; p.film_rows = film_rows;
+    p.y = y; p.B = batch; p.L = L; p.nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    p.H = cfg->hidden; p.kh = g.kh; p.dirs = g.dirs; p.c_out = cfg->c_out;
+    p.per_seq = (!film_row && film_rows > 1) ? 1 : 0;
+    const size_t ntask = (size_t)L * p.nbb;
+    int blocks = (int)((ntask + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    const size_t shm = (size_t)3 * g.dirs * g.kh * 16 * sizeof(float);
+    hipLaunchKernelGGL(td_head_wide_kernel, dim3(blocks), dim3(256), shm, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
