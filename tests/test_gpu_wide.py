@@ -94,3 +94,44 @@ def test_wide_sample_chain_matches_stepwise(dev):
     np.testing.assert_array_equal(a, b)
     assert a.shape == (B, 8, L) and np.isfinite(a).all()
     assert ((a[:, cat] == 0) | (a[:, cat] == 1)).all() and a[:, num].min() >= 0 and a[:, num].max() <= 1
+
+
+# (H, layers, dirs, gru, C, n_num, B, L)
+WIDE_TRAIN = [
+    (512, 2, 2, 0, 14, 4, 37, 8),     # bidirectional, head backward with parameters in LDS
+    (320, 2, 2, 1, 9, 7, 33, 6),      # GRU, padded unit blocks
+    (1024, 2, 2, 0, 9, 7, 20, 5),     # D*H = 2048: head backward reads its parameters from L2, 4 unit blocks per sweep wave
+    (768, 2, 1, 0, 23, 7, 5, 6),      # c_out > 16
+]
+
+
+@pytest.mark.parametrize("H,layers,dirs,gru,C,n_num,B,L", WIDE_TRAIN)
+def test_wide_denoiser_backward(H, layers, dirs, gru, C, n_num, B, L, dev):
+    """Wide training path: the saving forward equals the inference forward bit for bit; parameter gradients against
+    the fp32 oracle's BPTT within the bf16 bound (3 % of each tensor's largest entry)."""
+    sd = random_state(H, C, layers, dirs, gru, seed=H + 7)
+    den = den_kernels(sd, dev)
+    x, t, rng = _inputs(B, C, L, n_num, seed=H + 1)
+    gy = (rng.standard_normal((B, C, L)) / (B * L)).astype(np.float32)
+    film = den.time_film(cu(t, dev))
+    y_inf = den.forward(cu(x, dev), film=film).cpu().numpy()
+    y_tr = den.forward_train(cu(x, dev), film).cpu().numpy()
+    np.testing.assert_array_equal(y_tr, y_inf)
+    g_layer, g_misc, g_film = den.backward(cu(gy, dev), film)
+    _, _, ref = orc.Denoiser(sd).backward(x, t, gy)
+    for key, got in list(zip(den._lkeys, g_layer)) + list(g_misc.items()):
+        assert _rel(got.cpu().numpy(), ref[key]) < 3e-2, (key, _rel(got.cpu().numpy(), ref[key]))
+    np.testing.assert_allclose(g_film.sum(0).cpu().numpy(), ref["rnn.time_mlp.1.bias"], rtol=3e-2,
+                               atol=3e-2 * np.abs(ref["rnn.time_mlp.1.bias"]).max())
+
+
+def test_wide_training_unsupported_is_loud(dev):
+    """c_out > 16 together with dirs * hidden > 1024 exceeds the head backward's LDS accumulators: a clear error."""
+    from timediff_amd import _lib
+    sd = random_state(1024, 23, 1, 2, 0, seed=1)
+    den = den_kernels(sd, dev)
+    x, t, rng = _inputs(4, 23, 3, 7, seed=2)
+    film = den.time_film(cu(t, dev))
+    den.forward_train(cu(x, dev), film)
+    with pytest.raises(_lib.TimediffError, match="not supported"):
+        den.backward(cu(np.zeros((4, 23, 3), np.float32), dev), film)

@@ -230,23 +230,31 @@ struct TdHeadBwdParams {
     int B, L, nbb, H, hpad, kh, dirs, c_out;
 };
 
-template <int CMAX>
+// ROG: the read-only parameter copies (LayerNorm affine, fc_w) stay in global memory / L2 instead of LDS, which then
+// holds only the accumulators: (2 + CMAX) * D * Hpad floats (wide hidden sizes)
+template <int CMAX, bool ROG>
 __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float hl[];
     const int DHP = p.dirs * p.hpad, DH = p.dirs * p.H;
     float *s_lnw = hl, *s_lnb = hl + DHP, *s_fcw = hl + 2 * DHP;
-    float *a_lnw = s_fcw + CMAX * DHP, *a_lnb = a_lnw + DHP, *a_fcw = a_lnb + DHP, *a_fcb = a_fcw + CMAX * DHP;
+    float *a_lnw = ROG ? hl : s_fcw + CMAX * DHP, *a_lnb = a_lnw + DHP, *a_fcw = a_lnb + DHP, *a_fcb = a_fcw + CMAX * DHP;
     for (int i = threadIdx.x; i < DHP; i += 256) {
         const int d = i / p.hpad, unit = i % p.hpad;
         const bool ok = unit < p.H;
-        s_lnw[i] = ok ? p.ln_w[d * p.H + unit] : 0.f;
-        s_lnb[i] = ok ? p.ln_b[d * p.H + unit] : 0.f;
+        if constexpr (!ROG) {
+            s_lnw[i] = ok ? p.ln_w[d * p.H + unit] : 0.f;
+            s_lnb[i] = ok ? p.ln_b[d * p.H + unit] : 0.f;
+        }
         a_lnw[i] = 0.f; a_lnb[i] = 0.f;
         for (int c = 0; c < CMAX; ++c) {
-            s_fcw[c * DHP + i] = (ok && c < p.c_out) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
+            if constexpr (!ROG) s_fcw[c * DHP + i] = (ok && c < p.c_out) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
             a_fcw[c * DHP + i] = 0.f;
         }
     }
+    // parameter reads for a valid unit (ip: padded index, feat: index in the parameter tensors)
+    auto lnw = [&](int ip, int feat) { return ROG ? p.ln_w[feat] : s_lnw[ip]; };
+    auto lnb = [&](int ip, int feat) { return ROG ? p.ln_b[feat] : s_lnb[ip]; };
+    auto fcw = [&](int c, int ip, int feat) { return ROG ? (c < p.c_out ? p.fc_w[(size_t)c * DH + feat] : 0.f) : s_fcw[c * DHP + ip]; };
     if (threadIdx.x < CMAX) a_fcb[threadIdx.x] = 0.f;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
@@ -294,13 +302,13 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
                 if (unit >= p.H) continue;
                 const int ip = d * p.hpad + unit, feat = d * p.H + unit;
                 const float xh = ((float)v[j] - mu) * rstd;
-                const float lnout = xh * s_lnw[ip] + s_lnb[ip];
+                const float lnout = xh * lnw(ip, feat) + lnb(ip, feat);
                 const float sc1 = film[feat] + 1.0f;
                 const float yf = lnout * sc1 + film[DH + feat];
                 float dyf = 0.f;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) {
-                    dyf += g[c] * s_fcw[c * DHP + ip];
+                    dyf += g[c] * fcw(c, ip, feat);
                     if (c < p.c_out && valid) atomicAdd(&a_fcw[c * DHP + ip], g[c] * yf);
                 }
                 if (valid) {
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
                     const float dln = dyf * sc1;
                     atomicAdd(&a_lnw[ip], dln * xh);
                     atomicAdd(&a_lnb[ip], dln);
-                    const float dxh = dln * s_lnw[ip];
+                    const float dxh = dln * lnw(ip, feat);
                     m1 += dxh;
                     m2 += dxh * xh;
                 }
@@ -339,8 +347,8 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
                     const float xh = ((float)v[j] - mu) * rstd;
                     float dyf = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) dyf += g[c] * s_fcw[c * DHP + ip];
-                    const float dxh = dyf * (film[feat] + 1.0f) * s_lnw[ip];
+                    for (int c = 0; c < CMAX; ++c) dyf += g[c] * fcw(c, ip, feat);
+                    const float dxh = dyf * (film[feat] + 1.0f) * lnw(ip, feat);
                     dh = rstd * (dxh - m1 - xh * m2);
                 }
                 o[j] = (__bf16)dh;
@@ -504,32 +512,40 @@ struct TdSweepParams {
     int slab[4];
 };
 
+// WIDE (more than 8 unit blocks, rnn_wide.hip's hidden sizes): wave w owns the unit blocks w, w + 8, ... (UPW of
+// them), and d a_t (up to 256 KiB per step) is exchanged through the copy that goes to HBM anyway instead of LDS:
+// written, fenced, barrier, then read back from L2 as the B operand.
+template <int UPW, bool WIDE>
 __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const TdBpttParams &p = q.b;
     const int bblk = blockIdx.x, d = blockIdx.y;
-    const int u = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, m = lane & 31;   // wave = unit block
-    const bool mine = u < p.nu;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, m = lane & 31;
     const size_t stage_bytes = (size_t)4 * p.kh * TD_FRAG_BYTES;
     const size_t cols = (size_t)p.L * p.nbb * 32;
     const int hpad = p.kh * 16;
-    f32x4 dh[4], carry[4];   // accumulator rows 4k .. 4k+3
+    f32x4 dh[UPW][4], carry[UPW][4];   // accumulator rows 4k .. 4k+3 of each owned unit block
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { dh[k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const bf16x8 *wp = (const bf16x8 *)(q.wt + (size_t)d * q.wt_dir + (size_t)(mine ? u : 0) * q.nterm * p.kh * TD_FRAG_BYTES) + lane;
+    for (int i = 0; i < UPW; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dh[i][k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[i][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     for (int s = 0; s < p.L; ++s) {
         const int pos = p.L - 1 - s;                   // position in the direction's forward order
         const int l = d ? p.L - 1 - pos : pos;
         const int lprev = d ? l + 1 : l - 1;           // the step processed before l in the forward pass
         const bool has_prev = pos > 0;
-        char *dab = sm + (size_t)(s & 1) * stage_bytes;
-        if (mine) {
+        char *dab = WIDE ? p.daf + (size_t)d * p.daf_dir + ((size_t)l * p.nbb + bblk) * stage_bytes
+                         : sm + (size_t)(s & 1) * stage_bytes;
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = w + 8 * i;
+            if (u >= p.nu) continue;
             for (int sidx = 0; sidx < p.n_src; ++sidx) {
                 const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
                 const bf16x8 a = gp[0], b = gp[64];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { dh[j >> 2][j & 3] += (float)a[j]; dh[2 + (j >> 2)][j & 3] += (float)b[j]; }
+                for (int j = 0; j < 8; ++j) { dh[i][j >> 2][j & 3] += (float)a[j]; dh[i][2 + (j >> 2)][j & 3] += (float)b[j]; }
             }
             const f32x4 *sv = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16);
             const f32x4 *svp = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16);
@@ -541,25 +557,25 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * k + e;
-                    const float g = dh[k][e], prev = pv[e];
+                    const float g = dh[i][k][e], prev = pv[e];
                     if (!p.gru) {
                         const float ig = s0[e], fg = s1[e], gg = s2[e], og = s3[e], cv = s4[e];
                         const float tc = td_tanh(cv);
-                        const float dcv = carry[k][e] + g * og * (1.0f - tc * tc);
+                        const float dcv = carry[i][k][e] + g * og * (1.0f - tc * tc);
                         da[0][r] = dcv * gg * ig * (1.0f - ig);
                         da[1][r] = dcv * prev * fg * (1.0f - fg);
                         da[2][r] = dcv * ig * (1.0f - gg * gg);
                         da[3][r] = g * tc * og * (1.0f - og);
-                        carry[k][e] = dcv * fg;
+                        carry[i][k][e] = dcv * fg;
                     } else {
                         const float rg = s0[e], zg = s1[e], ng = s2[e], hn = s3[e];
-                        const float dht = g + carry[k][e];
+                        const float dht = g + carry[i][k][e];
                         const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
                         da[0][r] = dan * hn * rg * (1.0f - rg);
                         da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
                         da[2][r] = dan;
                         da[3][r] = dan * rg;
-                        carry[k][e] = dht * zg;
+                        carry[i][k][e] = dht * zg;
                     }
                 }
             }
@@ -568,12 +584,14 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                 bf16x8 a, b;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { a[j] = (__bf16)da[gi][j]; b[j] = (__bf16)da[gi][8 + j]; }
-                bf16x8 *lp = (bf16x8 *)(dab + ((size_t)gi * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-                lp[0] = a;
-                lp[64] = b;
                 bf16x8 *fp = (bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
                 fp[0] = a;
                 fp[64] = b;
+                if constexpr (!WIDE) {
+                    bf16x8 *lp = (bf16x8 *)(dab + ((size_t)gi * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+                    lp[0] = a;
+                    lp[64] = b;
+                }
                 __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -582,19 +600,26 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                 }
             }
         }
-        __syncthreads();   // d a_t of every unit block is in LDS (the other buffer is free again two steps on)
-        if (mine && s + 1 < p.L) {
-            f32x16 acc;
+        if constexpr (WIDE) __threadfence();   // the fragments must be in L2 before another wave reads them back
+        __syncthreads();   // d a_t of every unit block is published (LDS: the other buffer is free again two steps on)
+        if (s + 1 < p.L) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int term = 0; term < q.nterm; ++term) {
-                const bf16x8 *bp = (const bf16x8 *)(dab + (size_t)q.slab[term] * p.kh * TD_FRAG_BYTES) + lane;
-                const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
+            for (int i = 0; i < UPW; ++i) {
+                const int u = w + 8 * i;
+                if (u >= p.nu) continue;
+                const bf16x8 *wp = (const bf16x8 *)(q.wt + (size_t)d * q.wt_dir + (size_t)u * q.nterm * p.kh * TD_FRAG_BYTES) + lane;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int term = 0; term < q.nterm; ++term) {
+                    const bf16x8 *bp = (const bf16x8 *)(dab + (size_t)q.slab[term] * p.kh * TD_FRAG_BYTES) + lane;
+                    const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
 #pragma unroll 16
-                for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
-            }
+                    for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dh[r >> 2][r & 3] = acc[r];
+                for (int r = 0; r < 16; ++r) dh[i][r >> 2][r & 3] = acc[r];
+            }
         }
     }
 }
@@ -690,16 +715,22 @@ extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, cons
         int blocks = (int)((ntask + 3) / 4);
         if (blocks > 1024) blocks = 1024;
         const int DHP = D * g.hpad;
-        if (cfg->c_out <= 16) {
-            const size_t shm = ((size_t)(4 + 2 * 16) * DHP + 16) * sizeof(float);
-            TD_HIP(hipFuncSetAttribute((const void *)td_head_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(td_head_bwd_kernel<16>, dim3(blocks), dim3(256), shm, stream, p);
-        } else {
-            const size_t shm = ((size_t)(4 + 2 * 32) * DHP + 32) * sizeof(float);
-            TD_HIP(hipFuncSetAttribute((const void *)td_head_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(td_head_bwd_kernel<32>, dim3(blocks), dim3(256), shm, stream, p);
+        const size_t lds_max = 160 * 1024;
+        auto launch = [&](auto kern, size_t shm) -> int {
+            TD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, stream, p);
+            TD_LAUNCH_CHECK();
+            return TD_OK;
+        };
+        const int cm = cfg->c_out <= 16 ? 16 : 32;
+        const size_t shm_full = ((size_t)(4 + 2 * cm) * DHP + cm) * sizeof(float), shm_acc = ((size_t)(2 + cm) * DHP + cm) * sizeof(float);
+        if (shm_full <= lds_max) rc = cm == 16 ? launch(td_head_bwd_kernel<16, false>, shm_full) : launch(td_head_bwd_kernel<32, false>, shm_full);
+        else if (shm_acc <= lds_max) rc = cm == 16 ? launch(td_head_bwd_kernel<16, true>, shm_acc) : launch(td_head_bwd_kernel<32, true>, shm_acc);
+        else {
+            td_set_error("training with c_out = %d > 16 and dirs * hidden = %d > 1024 is not supported by this build", cfg->c_out, DH);
+            return TD_ERR_UNSUPPORTED;
         }
-        TD_LAUNCH_CHECK();
+        if (rc != TD_OK) return rc;
     }
 
     // ---- layers, top down ------------------------------------------------------------------------
@@ -719,9 +750,15 @@ extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, cons
             p.s = 0; p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
             q.wt = wT; q.wt_dir = packT_dir; q.nterm = G;
             q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
-            const size_t shm = (size_t)2 * 4 * g.kh * TD_FRAG_BYTES;
-            TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(td_bptt_sweep_kernel, dim3(t.nbb, D), dim3(512), shm, stream, q);
+            if (g.nu <= 8) {
+                const size_t shm = (size_t)2 * 4 * g.kh * TD_FRAG_BYTES;
+                TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL((td_bptt_sweep_kernel<1, false>), dim3(t.nbb, D), dim3(512), shm, stream, q);
+            } else if (g.nu <= 16) {
+                hipLaunchKernelGGL((td_bptt_sweep_kernel<2, true>), dim3(t.nbb, D), dim3(512), 0, stream, q);
+            } else {
+                hipLaunchKernelGGL((td_bptt_sweep_kernel<4, true>), dim3(t.nbb, D), dim3(512), 0, stream, q);
+            }
             TD_LAUNCH_CHECK();
         }
         // gradient for the layer below: d x = W_ih^T d a, all steps at once
