@@ -115,6 +115,16 @@ TD_API int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed, co
 TD_API int td_rnn_backward(const td_rnn_config *cfg, const void *packT, const float *const *misc_host, const float *film,
                     const float *grad_y, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer_host,
                     float *const *grad_misc_host, float *grad_film, void *stream);
+/* td_rnn_backward with a host callback for data-parallel training (the reference gets the same overlap from DDP's
+ * bucketed all-reduce inside accelerator.backward, et_diff.py:237): `layer_done(l, user)` is called on the calling
+ * thread right after the last kernel that writes layer l's parameter gradients has been ENQUEUED on `stream`
+ * (l = layers first, for the LayerNorm / fc gradients; then layers-1 .. 0).  The callback typically records an
+ * event on `stream` and starts that layer's gradient all-reduce on another stream behind it, while the
+ * layers below are still being differentiated.  layer_done == NULL: plain td_rnn_backward. */
+typedef void (*td_layer_done_fn)(int32_t layer, void *user);
+TD_API int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, const float *const *misc_host, const float *film,
+                       const float *grad_y, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer_host,
+                       float *const *grad_misc_host, float *grad_film, td_layer_done_fn layer_done, void *user, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Mixed diffusion: models/ETDiff/mixed_diffusion.py MixedDiffusion (:68-454); n_cat = 0 gives

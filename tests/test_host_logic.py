@@ -143,3 +143,21 @@ def test_dataset_cache_roundtrip(tmp_path):
     ok = ~torch.isnan(raw[:, :, :8]).numpy()
     np.testing.assert_allclose(back[:, [0, 2, 3]][ok[:, [0, 2, 3]]], raw[:, [0, 2, 3], :8].numpy()[ok[:, [0, 2, 3]]], rtol=1e-4,
                                atol=1e-4)
+
+
+def test_layer_slices_and_uncovered_ranges():
+    """The flat gradient buffer's per-layer all-reduce slices (ETDiff._layer_reduce) and what is left for the end."""
+    import torch.nn as nn
+    from timediff_amd.parallel import layer_slices, uncovered_ranges
+    m = nn.ModuleDict({"model": nn.ModuleDict({"pre": nn.Linear(3, 2), "rnn": nn.ModuleDict({"rnn": nn.LSTM(5, 4, 3, bidirectional=True)}),
+                                               "fc": nn.Linear(8, 5)})})
+    names = [n for n, _ in m.named_parameters()]
+    sizes = [p.numel() for p in m.parameters()]
+    sl = layer_slices(names, sizes, 3)
+    per_layer = [2 * (16 * (5 if l == 0 else 8) + 16 * 4 + 32) for l in range(3)]
+    assert sl[0][0] == 3 * 2 + 2 and [b - a for a, b in sl] == per_layer
+    assert sl[0][1] == sl[1][0] and sl[1][1] == sl[2][0]
+    n = sum(sizes)
+    assert uncovered_ranges(n, [sl[2], sl[0], sl[1]]) == [(0, sl[0][0]), (sl[2][1], n)]
+    assert uncovered_ranges(n, []) == [(0, n)]
+    assert uncovered_ranges(10, [(0, 4), (4, 10)]) == []

@@ -42,6 +42,9 @@ _lib = None
 
 _P = C.c_void_p
 _I = C.c_int32
+# td_layer_done_fn (include/timediff_hip.h): host callback of td_rnn_backward_cb
+LAYER_DONE_FN = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
+
 _SIGS = {
     "td_version": (C.c_int, []),
     "td_last_error": (C.c_char_p, []),
@@ -57,6 +60,8 @@ _SIGS = {
     "td_rnn_forward_train": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, _P, _P]),
     "td_rnn_backward": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, C.POINTER(_P),
                                   C.POINTER(_P), _P, _P]),
+    "td_rnn_backward_cb": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, C.POINTER(_P),
+                                     C.POINTER(_P), _P, LAYER_DONE_FN, _P, _P]),
     "td_q_sample_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, Rng, _P, _P, _P, _P, _P]),
     "td_mixed_loss_workspace_bytes": (C.c_size_t, [C.POINTER(DiffusionConfig), _I]),
     "td_mixed_loss": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),

@@ -19,6 +19,13 @@ class _DenoiserFn(torch.autograd.Function):
     def backward(ctx, grad_y):
         (film,) = ctx.saved_tensors
         k = ctx.module.kernels()
+        sink = getattr(ctx.module, "_grad_sink", None)
+        if sink is not None:
+            # the trainer's flat gradient buffer: the kernels accumulate straight into the .grad views (no
+            # AccumulateGrad pass), and the trainer may start a layer's all-reduce while the layers below are
+            # still being differentiated (et_diff.py: ETDiff._layer_reduce)
+            _, _, g_film = k.backward(grad_y.contiguous(), film, sink=sink["tensors"], on_layer_done=sink.get("on_layer_done"))
+            return (None, None, g_film) + (None,) * (len(k._lkeys) + len(_lib.MISC_KEYS[6:]))
         g_layer, g_misc, g_film = k.backward(grad_y.contiguous(), film)
         tail = [g_misc[key] for key in _lib.MISC_KEYS[6:]]
         return (None, None, g_film, *g_layer, *tail)

@@ -90,7 +90,7 @@ class RNN(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            setattr(new, k, None if k in ("_kernels", "_kernels_version") else copy.deepcopy(v, memo))
+            setattr(new, k, None if k in ("_kernels", "_kernels_version", "_grad_sink") else copy.deepcopy(v, memo))
         return new
 
     def forward(self, x, time, x_self_cond=None):

@@ -688,6 +688,14 @@ __global__ __launch_bounds__(256) void td_bias_reduce_kernel(const __bf16 *A, si
 extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
                                const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
                                float *const *grad_layer, float *const *grad_misc, float *grad_film, void *stream_) {
+    return td_rnn_backward_cb(cfg, packT, misc, film, grad_y, batch, seq_len, workspace, grad_layer, grad_misc, grad_film,
+                              nullptr, nullptr, stream_);
+}
+
+extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                                  const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
+                                  float *const *grad_layer, float *const *grad_misc, float *grad_film,
+                                  td_layer_done_fn layer_done, void *user, void *stream_) {
     TD_REQUIRE(cfg && packT && misc && film && grad_y && workspace && grad_layer && grad_misc && grad_film, "NULL argument");
     TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
     TdRnnGeom g;
@@ -732,6 +740,7 @@ extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, cons
         }
         if (rc != TD_OK) return rc;
     }
+    if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
 
     // ---- layers, top down ------------------------------------------------------------------------
     const int KT = D * g.kh;
@@ -815,6 +824,7 @@ extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, cons
                 }
             }
         }
+        if (layer_done) layer_done(l, user);   // every kernel that writes layer l's parameter gradients is enqueued
     }
     return TD_OK;
 }

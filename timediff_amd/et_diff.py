@@ -5,7 +5,8 @@ keywords, `.train()`, `.save_weights()`, `.load(path)`, `.ema.ema_model`, `.samp
 What differs underneath (MI355X-first, same arithmetic):
   * no accelerate / DDP wrappers: one process per GPU; with WORLD_SIZE > 1 the global batch is split
     across ranks (split_batches=True semantics, et_diff.py:45) and the flat fp32 gradient buffer is
-    all-reduced (mean) over RCCL once per optimizer step, on a side stream;
+    all-reduced (mean) over RCCL once per optimizer step on a side stream, one slice per recurrent layer,
+    each started as soon as that layer's gradient kernels are enqueued (overlapped with the BPTT below it);
   * all parameters, gradients, Adam moments and EMA weights live in flat fp32 buffers: grad-norm, clip,
     Adam and the EMA update are two fused kernel launches (td_grad_norm, td_clip_adam_ema);
   * the loss is read back once per optimizer step, not once per micro-batch.
@@ -28,6 +29,7 @@ from torch.utils.data import DataLoader
 from . import _lib
 from ._lib import check, lib, ptr
 from .data import cycle, exists
+from .parallel import layer_slices, uncovered_ranges
 
 logging.basicConfig(filename=None, format="[%(levelname)s:%(asctime)s] %(message)s", level=logging.INFO)
 
@@ -97,7 +99,9 @@ class ETDiff(nn.Module):
         torch.cuda.set_device(local_rank)
         self._device = torch.device("cuda", local_rank)
         if self.world > 1 and not torch.distributed.is_initialized():
-            torch.distributed.init_process_group("nccl", device_id=self._device)
+            # "nccl" is RCCL on ROCm; TIMEDIFF_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+            backend = os.environ.get("TIMEDIFF_DIST_BACKEND", "nccl")
+            torch.distributed.init_process_group(backend, **({"device_id": self._device} if backend == "nccl" else {}))
         print(f"*** Using device: {self._device} ***", file=sys.stderr)
 
         self.timer = timeit.default_timer
@@ -140,6 +144,20 @@ class ETDiff(nn.Module):
         self._norm = torch.zeros(1, dtype=torch.float32, device=self._device)
         self._norm_ws = torch.empty(lib().td_grad_norm_workspace_bytes(), dtype=torch.uint8, device=self._device)
         self._comm_stream = torch.cuda.Stream(device=self._device) if self.world > 1 else None
+        # The denoiser's backward accumulates straight into the flat gradient buffer (no AccumulateGrad pass); with
+        # several ranks each recurrent layer's slice is all-reduced as soon as its gradient kernels are enqueued,
+        # behind an event, on the communication stream, while BPTT goes on in the layers below.
+        names = [n for n, _ in self.model.named_parameters()]
+        den = getattr(self.model, "model", None)
+        self._sink = None
+        self._reduced = []
+        self._overlap = os.environ.get("TIMEDIFF_DP_OVERLAP", "1") != "0"
+        if den is not None and hasattr(den, "kernels"):
+            by_name = dict(self.model.named_parameters())
+            self._sink = {"tensors": {n: by_name["model." + n].grad for n, _ in den.named_parameters()}, "on_layer_done": None}
+            den._grad_sink = self._sink
+            self._n_layers = den.rnn.rnn.num_layers
+            self._layer_slices = layer_slices(names, [p.numel() for p in self.params], self._n_layers)
         self.opt_step = 0
         self.step = 0
 
@@ -192,14 +210,33 @@ class ETDiff(nn.Module):
         self.ema.load_state_dict(data["ema"], strict=False)
 
     # -- one optimizer step --------------------------------------------------------------------------
+    def _reduce_slice(self, a, b):
+        """Mean over ranks of flat_grad[a:b], enqueued on the communication stream."""
+        import torch.distributed as dist
+        with torch.cuda.stream(self._comm_stream):
+            g = self.flat_grad[a:b]
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            g.div_(self.world)
+
+    def _layer_reduce(self, layer):
+        """td_rnn_backward_cb's callback on the last micro-batch: layer `layer`'s gradient kernels are all enqueued."""
+        if layer >= self._n_layers:
+            return      # LayerNorm / fc: reduced with the rest of the small tensors at the end
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._comm_stream.wait_event(ev)
+        a, b = self._layer_slices[layer]
+        self._reduce_slice(a, b)
+        self._reduced.append((a, b))
+
     def _all_reduce_grads(self):
+        """Whatever the per-layer reductions have not covered (everything when overlap is off), then join."""
         if self.world == 1:
             return
-        import torch.distributed as dist
         self._comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm_stream):
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.flat_grad.div_(self.world)
+        for a, b in uncovered_ranges(self.flat_grad.numel(), self._reduced):
+            self._reduce_slice(a, b)
+        self._reduced = []
         torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def _optimizer_step(self, update_ema):
@@ -226,7 +263,10 @@ class ETDiff(nn.Module):
         """gradient_accumulate_every micro-batches + one optimizer step; -> the step's loss (device scalar)."""
         ga = self.gradient_accumulate_every
         total = torch.zeros((), dtype=torch.float32, device=self.device)
-        for _ in range(ga):
+        for i in range(ga):
+            if self._sink is not None:
+                overlap = self.world > 1 and self._overlap and i == ga - 1
+                self._sink["on_layer_done"] = self._layer_reduce if overlap else None
             data = next(self.dl).to(self.device, non_blocking=True)
             loss = self.model(data) / ga
             total += loss.detach()

@@ -40,3 +40,33 @@ def gather_samples(local, total, group=None):
         return torch.cat(parts, dim=0)
     dist.send(local.contiguous(), dst=0, group=group)
     return None
+
+
+def layer_slices(names, sizes, layers, prefix="model.rnn.rnn."):
+    """[(begin, end)] per recurrent layer in a flat buffer that holds the parameters `names` (sizes `sizes`) back to
+    back: nn.LSTM / nn.GRU register weight_ih, weight_hh, bias_ih, bias_hh of a layer (then its _reverse twins)
+    contiguously, so each layer is ONE slice = one all-reduce."""
+    off, spans = 0, [None] * layers
+    for name, n in zip(names, sizes):
+        if name.startswith(prefix) and "_l" in name:
+            l = int(name[len(prefix):].split("_l")[1].split("_")[0])
+            a, b, tot = spans[l] or (off, off, 0)
+            spans[l] = (min(a, off), max(b, off + n), tot + n)
+        off += n
+    out = []
+    for l, sp in enumerate(spans):
+        assert sp is not None and sp[1] - sp[0] == sp[2], f"layer {l}'s parameters are not contiguous in the flat buffer"
+        out.append((sp[0], sp[1]))
+    return out
+
+
+def uncovered_ranges(n, done):
+    """The parts of [0, n) that no (begin, end) of `done` covers, in order."""
+    out, pos = [], 0
+    for a, b in sorted(done):
+        if a > pos:
+            out.append((pos, a))
+        pos = max(pos, b)
+    if pos < n:
+        out.append((pos, n))
+    return out
