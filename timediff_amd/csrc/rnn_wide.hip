@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
         const bf16x8 *xp = (const bf16x8 *)(p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES) + lane;
         bf16x8 *op = (bf16x8 *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES) + lane;
 
-        tdw_static_for<NUW>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+        // One copy of the block body: the loop over this wave's unit blocks stays rolled, and the state registers
+        // ROTATE by one block per iteration (16 * NUW moves against >= 292 MFMAs), so the block being worked on is
+        // always state[0] and register indices stay static.
+#pragma unroll 1
+        for (int i = 0; i < NUW; ++i) {
             const int u = wave * NUW + i;
             const bf16x8 *wa = wdir + (size_t)u * FU * 64;
             f32x16 acc[4];
@@ -65,46 +68,66 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
-            // chunk c of the stream after the bias fragments: weight fragments + the B operands they meet
+            // Two-chunk software pipeline over the weight stream after the bias fragments; a chunk = 4 k-steps =
+            // CH weight fragments + the 4 B operands they meet (h_{t-1} from LDS, then the layer input from L2).
+            // Straight-line bodies (no branch between a load and its use), so the compiler's counted vmcnt waits
+            // let chunk c+1's loads stay in flight under chunk c's MFMAs.
             bf16x8 A0[CH], A1[CH], B0[4], B1[4];
-            auto load = [&](int c, bf16x8(&A)[CH], bf16x8(&B)[4]) {
+            auto ldA = [&](int c, bf16x8(&A)[CH]) {
                 const bf16x8 *wp = wa + (size_t)(4 + c * CH) * 64;
 #pragma unroll
                 for (int j = 0; j < CH; ++j) A[j] = wp[j * 64];
-                if (4 * c < KH) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) B[k] = hcur[(4 * c + k) * 64];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) B[k] = xp[(4 * c - KH + k) * 64];
-                }
             };
-            auto compute = [&](int c, bf16x8(&A)[CH], bf16x8(&B)[4]) {
-                const bool rec = 4 * c < KH;
+            auto ldH = [&](int c, bf16x8(&B)[4]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) B[k] = hcur[(4 * c + k) * 64];
+            };
+            auto ldX = [&](int c, bf16x8(&B)[4]) {   // c counts from the first input chunk
+#pragma unroll
+                for (int k = 0; k < 4; ++k) B[k] = xp[(4 * c + k) * 64];
+            };
+            auto mma = [&](auto recc, bf16x8(&A)[CH], bf16x8(&B)[4]) {
+                constexpr bool rec = decltype(recc)::value;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        if (GRU && g == 2) {
-                            // n gate: the recurrent half accumulates apart (it is multiplied by r)
-                            if (rec) acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[3], 0, 0, 0);
-                            else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[2], 0, 0, 0);
-                        } else {
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[g], 0, 0, 0);
-                        }
+                        // GRU n gate: the recurrent half accumulates apart (it is multiplied by r)
+                        const int ai = (GRU && g == 2 && rec) ? 3 : g;
+                        acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[ai], 0, 0, 0);
                     }
             };
-            load(0, A0, B0);
+            constexpr std::true_type REC{};
+            constexpr std::false_type INP{};
+            const int NH = KH / 4, NX = KXF / 4;   // both even
+            ldA(0, A0); ldH(0, B0);
             // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden), hi + lo columns against ones
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[f * 64], ones, acc[f], 0, 0, 0);
-            for (int c = 0; c < NCH; c += 2) {   // NCH is even
-                load(c + 1, A1, B1);
-                compute(c, A0, B0);
-                if (c + 2 < NCH) load(c + 2, A0, B0);
-                compute(c + 1, A1, B1);
+#pragma unroll 1
+            for (int c = 0; c + 2 < NH; c += 2) {
+                ldA(c + 1, A1); ldH(c + 1, B1);
+                mma(REC, A0, B0);
+                ldA(c + 2, A0); ldH(c + 2, B0);
+                mma(REC, A1, B1);
             }
-            if constexpr (L0) {
+            ldA(NH - 1, A1); ldH(NH - 1, B1);
+            mma(REC, A0, B0);
+            if constexpr (!L0) {
+                ldA(NH, A0); ldX(0, B0);          // hand over to the input part without draining the pipeline
+                mma(REC, A1, B1);
+#pragma unroll 1
+                for (int c = 0; c + 2 < NX; c += 2) {
+                    ldA(NH + c + 1, A1); ldX(c + 1, B1);
+                    mma(INP, A0, B0);
+                    ldA(NH + c + 2, A0); ldX(c + 2, B0);
+                    mma(INP, A1, B1);
+                }
+                ldA(NH + NX - 1, A1); ldX(NX - 1, B1);
+                mma(INP, A0, B0);
+                mma(INP, A1, B1);
+            } else {
+                mma(REC, A1, B1);
                 // first layer: W = Whi + Wlo, x = xhi + xlo in bf16, the three leading products (rnn_layer.h)
                 const bf16x8 *wp = wa + (size_t)(4 + KH * NG) * 64;
                 for (int kx = 0; kx < kx0; ++kx) {
@@ -131,8 +154,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
                     const float ig = __builtin_amdgcn_rcpf(1.0f + e0), fg = __builtin_amdgcn_rcpf(1.0f + e1);
                     const float t2 = __builtin_amdgcn_rcpf(e2 + 1.0f), og = __builtin_amdgcn_rcpf(1.0f + e3);
                     const float gg = __builtin_fmaf(-2.0f, t2, 1.0f);
-                    const float cv = __builtin_fmaf(fg, state[i][r], ig * gg);
-                    state[i][r] = cv;
+                    const float cv = __builtin_fmaf(fg, state[0][r], ig * gg);
+                    state[0][r] = cv;
                     float t5 = __builtin_amdgcn_exp2f(P2L2E * cv);
                     t5 = __builtin_amdgcn_rcpf(t5 + 1.0f);
                     hv[r] = og * __builtin_fmaf(-2.0f, t5, 1.0f);
@@ -143,8 +166,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
                     float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[3][r], acc[2][r]));
                     t2 = __builtin_amdgcn_rcpf(t2 + 1.0f);
                     const float ng = __builtin_fmaf(-2.0f, t2, 1.0f);
-                    const float h = __builtin_fmaf(zg, state[i][r], (1.0f - zg) * ng);
-                    state[i][r] = h;
+                    const float h = __builtin_fmaf(zg, state[0][r], (1.0f - zg) * ng);
+                    state[0][r] = h;
                     hv[r] = h;
                     if constexpr (SAVE) { sv[0][r] = rg; sv[1][r] = zg; sv[2][r] = ng; sv[3][r] = acc[3][r] * (1.0f / P2L2E); sv[4][r] = h; }
                 }
@@ -165,7 +188,15 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
                     for (int q = 0; q < 4; ++q)
                         *(f32x4 *)(svb + k * 1024 + 4 * q) = f32x4{sv[k][4 * q], sv[k][4 * q + 1], sv[k][4 * q + 2], sv[k][4 * q + 3]};
             }
-        });
+            // rotate the state registers: the next block of this wave becomes state[0]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float first = state[0][r];
+#pragma unroll
+                for (int k = 0; k + 1 < NUW; ++k) state[k][r] = state[k + 1][r];
+                state[NUW - 1][r] = first;
+            }
+        }
         __syncthreads();   // h_t complete in LDS; every wave is done with h_{t-1}
     }
 }
