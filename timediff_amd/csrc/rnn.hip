@@ -11,7 +11,12 @@ extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
     return g.packed_bytes;
 }
 
-// workspace: [x0 fragments][act A][act B]
+// wide layers (rnn_wide.hip) keep the recurrent state of a step in a scratch region, one per direction
+static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
+    return g.nu > 8 ? (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.nu * 1024 * sizeof(float) : 0;
+}
+
+// workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]
 static void td_ws_layout(const TdRnnGeom &g, int batch, int L, size_t *x0_bytes, size_t *act_bytes) {
     size_t nbb = (size_t)td_cdiv(batch, TD_WAVE_BATCH);
     *x0_bytes = (size_t)L * nbb * g.g0.xfr * TD_FRAG_BYTES;
@@ -23,7 +28,7 @@ extern "C" size_t td_rnn_workspace_bytes(const td_rnn_config *cfg, int32_t batch
     if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0 || seq_len <= 0) return 0;
     size_t x0, act;
     td_ws_layout(g, batch, seq_len, &x0, &act);
-    return x0 + 2 * act;
+    return x0 + 2 * act + g.dirs * td_state_dir_bytes(g, batch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,7 +441,7 @@ void td_profile_end(int slot, void *stream);
 // Runs pack-input + all recurrent layers.  acts[l] receives layer l's output fragments; saves[l] (training)
 // the per-step gate activations.  Inference ping-pongs two activation buffers.
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
-                         char *const *acts, float *const *saves, hipStream_t stream) {
+                         char *const *acts, float *const *saves, float *state, hipStream_t stream) {
     TdRnnGeom g;
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
@@ -459,6 +464,8 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
         p.L = L; p.nbb = nbb; p.dirs = g.dirs;
         p.save = saves ? saves[l] : nullptr;
         p.save_dir_stride = (size_t)L * nbb * g.nu * 5 * 1024;
+        p.state = state;
+        p.state_dir_stride = td_state_dir_bytes(g, batch) / sizeof(float);
         const int kxsel = l == 0 ? g.kx0 : g.dirs;
         if (g.nu > 8) {
             const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
@@ -488,7 +495,7 @@ int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float 
     char *acts[16];
     for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
     *last_act = acts[cfg->layers - 1];
-    return td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, stream);
+    return td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, (float *)(actB + act_bytes), stream);
 }
 
 // Sampler path: the layer-0 fragments come straight from the diffusion state (z, class ids).
@@ -510,7 +517,7 @@ int td_rnn_run_layers_state(const td_rnn_config *cfg, const void *packed, const 
     char *acts[16];
     for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
     *last_act = acts[cfg->layers - 1];
-    return td_rnn_run_layers_ex(cfg, packed, nullptr, batch, L, x0, acts, nullptr, stream);
+    return td_rnn_run_layers_ex(cfg, packed, nullptr, batch, L, x0, acts, nullptr, (float *)(actB + act_bytes), stream);
 }
 
 template <int KT>

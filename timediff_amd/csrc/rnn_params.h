@@ -13,4 +13,7 @@ struct TdLayerParams {
     // [dir][l][bblk][u][5][64 lanes][16] fp32 in accumulator layout: LSTM i,f,g,o,c ; GRU r,z,n,(W_hn h + b_hn),h
     float *save;
     size_t save_dir_stride;  // floats
+    // wide layers (rnn_wide.hip) only: recurrent state between steps, [dir][bblk][u][64 lanes][16] fp32
+    float *state;
+    size_t state_dir_stride;  // floats
 };

@@ -17,7 +17,7 @@ int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, i
 }
 
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
-                         char *const *acts, float *const *saves, hipStream_t stream);
+                         char *const *acts, float *const *saves, float *state, hipStream_t stream);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
                 const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
 
@@ -56,10 +56,8 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
             t.daf[l][d] = take(t.daf_bytes);
             t.dapl[l][d] = take(4 * t.dapl_slab_elems * 2);
         }
-    for (int d = 0; d < 2; ++d) {
-        t.dhrec[d] = take((size_t)t.nbb * g.kh * TD_FRAG_BYTES);
-        t.dc[d] = take((size_t)t.nbb * g.nu * 1024 * sizeof(float));
-    }
+    for (int d = 0; d < 2; ++d) t.dhrec[d] = take((size_t)t.nbb * g.kh * TD_FRAG_BYTES);
+    for (int d = 0; d < 2; ++d) t.dc[d] = take((size_t)t.nbb * g.nu * 1024 * sizeof(float));   // back to back (a multiple of 256 B each)
     t.total = off;
     return t;
 }
@@ -119,7 +117,9 @@ extern "C" int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed
         acts[l] = ws + t.act[l];
         saves[l] = (float *)(ws + t.save[l]);
     }
-    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, stream);
+    // wide layers: the recurrent-state scratch is the d c carry region of the backward pass ([bblk][u][1024] fp32 per
+    // direction, contiguous: td_train_layout)
+    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream);
     if (rc != TD_OK) return rc;
     rc = td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, batch, nullptr, batch, seq_len, y, stream);
     if (rc != TD_OK) return rc;

@@ -2,10 +2,13 @@
 //
 // Above H = 256 the state of 32 sequences (cell state fp32 + h as B fragments) no longer fits one wave's
 // registers, so the decomposition of rnn_layer.h turns by 90 degrees: a workgroup (4 waves, one per SIMD)
-// owns ONE batch block of 32 sequences for all L steps and splits the hidden units: wave w owns the NUW
-// 32-unit blocks w*NUW .. w*NUW+NUW-1 (their cell state stays in its registers).  h_{t-1} of all units is the
-// B operand of every wave's recurrent k-steps and lives in LDS (double buffered, KH KiB each: one barrier per
-// step).  The weight fragments are the same packed stream rnn_layer.h reads ([unit block][bias | W_hh k-steps |
+// owns TDW_NB = 2 batch blocks of 32 sequences for all L steps and splits the hidden units: wave w owns the NUW
+// 32-unit blocks w*NUW .. w*NUW+NUW-1, for both batch blocks, so a weight fragment fetched from L2 feeds two
+// MFMAs.  The fp32 recurrent state of a block is kept in L2/HBM between steps (read a block of MFMAs ahead of its
+// use, 8 H bytes per sequence and step: nothing next to the weight stream), which leaves the registers to the
+// second set of accumulators.  h_{t-1} of all units is the B operand of every wave's recurrent k-steps and lives
+// in LDS (2 KH KiB <= 128 KiB, single buffered: h_t goes to the layer output first and is copied back into LDS
+// between two barriers).  The weight fragments are the same packed stream rnn_layer.h reads ([unit block][bias | W_hh k-steps |
 // W_ih k-steps][gate], td_pack_weights_kernel); each wave streams its own blocks' fragments L2 -> registers
 // through a two-chunk software pipeline (a chunk = 4 k-steps = 4*NG fragments).  The layer's input fragments
 // are read from L2/HBM as B operands with the chunk that uses them.
@@ -23,70 +26,92 @@ __device__ __forceinline__ void tdw_static_for(F &&f) {
     }
 }
 
+#define TDW_NB 2   // batch blocks (of 32 sequences) per workgroup: every weight fragment feeds TDW_NB MFMAs
+
 template <int NUW, bool L0, bool GRU, bool SAVE>
 __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
+    constexpr int NB = TDW_NB;
     constexpr int NG = GRU ? 3 : 4, NU = 4 * NUW, KH = 2 * NU, CH = 4 * NG;   // CH: weight fragments per chunk
-    extern __shared__ __attribute__((aligned(16))) char hlds[];                 // [2][KH] fragments
+    extern __shared__ __attribute__((aligned(16))) char hlds[];                 // [NB][KH] fragments: h_{t-1}
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = p.dirs == 2 ? (blockIdx.x & 1) : 0;
-    const int bb = p.dirs == 2 ? (blockIdx.x >> 1) : blockIdx.x;
+    const int tile = p.dirs == 2 ? (blockIdx.x >> 1) : blockIdx.x;
+    // an odd batch-block count leaves the last tile one block short: it repeats its first block (same inputs, same
+    // stores), so every wave runs the same instruction stream
+    int bbs[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bbs[n] = tile * NB + n < p.nbb ? tile * NB + n : p.nbb - 1;
     const int KXF = L0 ? 0 : p.in_frags;                 // input k-steps above the first layer (= dirs * KH)
     const int XFR0 = L0 ? 2 * kx0 : 0;                   // first layer: hi + lo fragments
     const int FU = 4 + (KH + (L0 ? XFR0 : KXF)) * NG;    // weight fragments per unit block
-    const int NCH = (KH + KXF) / 4;                      // pipelined chunks per unit block (KH, KXF: multiples of 8)
 
-    for (int i = tid; i < KH * 64; i += 256) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0 (buffer 0)
+    for (int i = tid; i < NB * KH * 64; i += 256) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0
     __syncthreads();
 
-    float state[NUW][16];   // LSTM: cell state; GRU: hidden state (fp32)
-#pragma unroll
-    for (int i = 0; i < NUW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) state[i][r] = 0.f;
     bf16x8 ones = {};
     if (lane < 32) { ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f; }
     const bf16x8 *wdir = (const bf16x8 *)(p.wpacked + (size_t)dir * p.dir_stride) + lane;
+    const bf16x8 *hl = (const bf16x8 *)hlds + lane;
 
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
-        const bf16x8 *hcur = (const bf16x8 *)(hlds + (size_t)(s & 1) * KH * TD_FRAG_BYTES) + lane;
-        bf16x8 *hnext = (bf16x8 *)(hlds + (size_t)((s + 1) & 1) * KH * TD_FRAG_BYTES) + lane;
-        const bf16x8 *xp = (const bf16x8 *)(p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES) + lane;
-        bf16x8 *op = (bf16x8 *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES) + lane;
+        const bf16x8 *xp[NB];
+        bf16x8 *op[NB];
+        float *stp[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            xp[n] = (const bf16x8 *)(p.xin + ((size_t)l * p.nbb + bbs[n]) * p.in_frags * TD_FRAG_BYTES) + lane;
+            op[n] = (bf16x8 *)(p.out + (((size_t)l * p.nbb + bbs[n]) * p.out_frags + dir * KH) * TD_FRAG_BYTES) + lane;
+            stp[n] = p.state + (size_t)dir * p.state_dir_stride + (size_t)bbs[n] * NU * 1024 + lane * 16;
+        }
 
-        // One copy of the block body: the loop over this wave's unit blocks stays rolled, and the state registers
-        // ROTATE by one block per iteration (16 * NUW moves against >= 292 MFMAs), so the block being worked on is
-        // always state[0] and register indices stay static.
 #pragma unroll 1
         for (int i = 0; i < NUW; ++i) {
             const int u = wave * NUW + i;
             const bf16x8 *wa = wdir + (size_t)u * FU * 64;
-            f32x16 acc[4];
+            // recurrent state of this block (LSTM: c, GRU: h, fp32): it lives in L2 / HBM between steps -- 8 H bytes
+            // per sequence and step, nothing next to the weight stream -- and is read here, a whole block of MFMAs
+            // ahead of its use (under the block's last chunks), so the register file keeps room for a second batch block's accumulators
+            f32x4 cst[NB][4];
+            auto ldState = [&]() {   // issued under the block's last two chunks of MFMAs
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+                    for (int q = 0; q < 4; ++q)
+                        cst[n][q] = s > 0 ? *(const f32x4 *)(stp[n] + (size_t)u * 1024 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            f32x16 acc[NB][4];
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[n][g][r] = 0.f;
 
             // Two-chunk software pipeline over the weight stream after the bias fragments; a chunk = 4 k-steps =
-            // CH weight fragments + the 4 B operands they meet (h_{t-1} from LDS, then the layer input from L2).
+            // CH weight fragments + the B operands they meet (h_{t-1} from LDS, then the layer input from L2).
             // Straight-line bodies (no branch between a load and its use), so the compiler's counted vmcnt waits
             // let chunk c+1's loads stay in flight under chunk c's MFMAs.
-            bf16x8 A0[CH], A1[CH], B0[4], B1[4];
+            bf16x8 A0[CH], A1[CH], B0[NB][4], B1[NB][4];
             auto ldA = [&](int c, bf16x8(&A)[CH]) {
                 const bf16x8 *wp = wa + (size_t)(4 + c * CH) * 64;
 #pragma unroll
                 for (int j = 0; j < CH; ++j) A[j] = wp[j * 64];
             };
-            auto ldH = [&](int c, bf16x8(&B)[4]) {
+            auto ldH = [&](int c, bf16x8(&B)[NB][4]) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) B[k] = hcur[(4 * c + k) * 64];
-            };
-            auto ldX = [&](int c, bf16x8(&B)[4]) {   // c counts from the first input chunk
+                for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) B[k] = xp[(4 * c + k) * 64];
+                    for (int k = 0; k < 4; ++k) B[n][k] = hl[(n * KH + 4 * c + k) * 64];
             };
-            auto mma = [&](auto recc, bf16x8(&A)[CH], bf16x8(&B)[4]) {
+            auto ldX = [&](int c, bf16x8(&B)[NB][4]) {   // c counts from the first input chunk
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) B[n][k] = xp[n][(4 * c + k) * 64];
+            };
+            auto mma = [&](auto recc, bf16x8(&A)[CH], bf16x8(&B)[NB][4]) {
                 constexpr bool rec = decltype(recc)::value;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -94,123 +119,145 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
                     for (int g = 0; g < NG; ++g) {
                         // GRU n gate: the recurrent half accumulates apart (it is multiplied by r)
                         const int ai = (GRU && g == 2 && rec) ? 3 : g;
-                        acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[k], acc[ai], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NB; ++n)
+                            acc[n][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k * NG + g], B[n][k], acc[n][ai], 0, 0, 0);
                     }
             };
             constexpr std::true_type REC{};
             constexpr std::false_type INP{};
             const int NH = KH / 4, NX = KXF / 4;   // both even
+            // PIN: the machine scheduler otherwise sinks each load next to its MFMA to save registers, which turns the
+            // pipeline into load -> wait -> 2 MFMAs per fragment
+#define TDW_PIN() __builtin_amdgcn_sched_barrier(0)
             ldA(0, A0); ldH(0, B0);
+            TDW_PIN();
             // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden), hi + lo columns against ones
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[f * 64], ones, acc[f], 0, 0, 0);
+            for (int f = 0; f < 4; ++f) {
+                const bf16x8 wb = wa[f * 64];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, ones, acc[n][f], 0, 0, 0);
+            }
 #pragma unroll 1
             for (int c = 0; c + 2 < NH; c += 2) {
-                ldA(c + 1, A1); ldH(c + 1, B1);
+                TDW_PIN(); ldA(c + 1, A1); ldH(c + 1, B1); TDW_PIN();
                 mma(REC, A0, B0);
-                ldA(c + 2, A0); ldH(c + 2, B0);
+                TDW_PIN(); ldA(c + 2, A0); ldH(c + 2, B0); TDW_PIN();
                 mma(REC, A1, B1);
             }
-            ldA(NH - 1, A1); ldH(NH - 1, B1);
+            TDW_PIN(); ldA(NH - 1, A1); ldH(NH - 1, B1); TDW_PIN();
             mma(REC, A0, B0);
             if constexpr (!L0) {
-                ldA(NH, A0); ldX(0, B0);          // hand over to the input part without draining the pipeline
+                TDW_PIN(); ldA(NH, A0); ldX(0, B0); TDW_PIN();   // hand over to the input part without draining the pipeline
                 mma(REC, A1, B1);
 #pragma unroll 1
                 for (int c = 0; c + 2 < NX; c += 2) {
-                    ldA(NH + c + 1, A1); ldX(c + 1, B1);
+                    TDW_PIN(); ldA(NH + c + 1, A1); ldX(c + 1, B1); TDW_PIN();
                     mma(INP, A0, B0);
-                    ldA(NH + c + 2, A0); ldX(c + 2, B0);
+                    TDW_PIN(); ldA(NH + c + 2, A0); ldX(c + 2, B0); TDW_PIN();
                     mma(INP, A1, B1);
                 }
-                ldA(NH + NX - 1, A1); ldX(NX - 1, B1);
+                TDW_PIN(); ldA(NH + NX - 1, A1); ldX(NX - 1, B1); TDW_PIN();
                 mma(INP, A0, B0);
+                TDW_PIN(); ldState(); TDW_PIN();
                 mma(INP, A1, B1);
             } else {
+                TDW_PIN(); ldState(); TDW_PIN();
                 mma(REC, A1, B1);
                 // first layer: W = Whi + Wlo, x = xhi + xlo in bf16, the three leading products (rnn_layer.h)
                 const bf16x8 *wp = wa + (size_t)(4 + KH * NG) * 64;
                 for (int kx = 0; kx < kx0; ++kx) {
-                    const bf16x8 xhi = xp[(2 * kx) * 64], xlo = xp[(2 * kx + 1) * 64];
+                    bf16x8 xhi[NB], xlo[NB];
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) { xhi[n] = xp[n][(2 * kx) * 64]; xlo[n] = xp[n][(2 * kx + 1) * 64]; }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         const bf16x8 whi = wp[(size_t)(2 * (kx * NG + g)) * 64], wlo = wp[(size_t)(2 * (kx * NG + g) + 1) * 64];
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi, acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            acc[n][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo[n], acc[n][g], 0, 0, 0);
+                            acc[n][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi[n], acc[n][g], 0, 0, 0);
+                            acc[n][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi[n], acc[n][g], 0, 0, 0);
+                        }
                     }
                 }
             }
 
             // gates (row r of the accumulator = unit 32u + (r&3) + 8(r>>2) + 4hf)
             constexpr float P2L2E = TD_GATE_SCALE_TANH;
-            float hv[16];
-            float sv[5][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (!GRU) {
-                    const float e0 = __builtin_amdgcn_exp2f(acc[0][r]), e1 = __builtin_amdgcn_exp2f(acc[1][r]);
-                    const float e2 = __builtin_amdgcn_exp2f(acc[2][r]), e3 = __builtin_amdgcn_exp2f(acc[3][r]);
-                    const float ig = __builtin_amdgcn_rcpf(1.0f + e0), fg = __builtin_amdgcn_rcpf(1.0f + e1);
-                    const float t2 = __builtin_amdgcn_rcpf(e2 + 1.0f), og = __builtin_amdgcn_rcpf(1.0f + e3);
-                    const float gg = __builtin_fmaf(-2.0f, t2, 1.0f);
-                    const float cv = __builtin_fmaf(fg, state[0][r], ig * gg);
-                    state[0][r] = cv;
-                    float t5 = __builtin_amdgcn_exp2f(P2L2E * cv);
-                    t5 = __builtin_amdgcn_rcpf(t5 + 1.0f);
-                    hv[r] = og * __builtin_fmaf(-2.0f, t5, 1.0f);
-                    if constexpr (SAVE) { sv[0][r] = ig; sv[1][r] = fg; sv[2][r] = gg; sv[3][r] = og; sv[4][r] = cv; }
-                } else {
-                    const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
-                    const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
-                    float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[3][r], acc[2][r]));
-                    t2 = __builtin_amdgcn_rcpf(t2 + 1.0f);
-                    const float ng = __builtin_fmaf(-2.0f, t2, 1.0f);
-                    const float h = __builtin_fmaf(zg, state[0][r], (1.0f - zg) * ng);
-                    state[0][r] = h;
-                    hv[r] = h;
-                    if constexpr (SAVE) { sv[0][r] = rg; sv[1][r] = zg; sv[2][r] = ng; sv[3][r] = acc[3][r] * (1.0f / P2L2E); sv[4][r] = h; }
+            for (int n = 0; n < NB; ++n) {
+                float hv[16];
+                float sv[5][16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float prev = cst[n][r >> 2][r & 3];
+                    if constexpr (!GRU) {
+                        const float e0 = __builtin_amdgcn_exp2f(acc[n][0][r]), e1 = __builtin_amdgcn_exp2f(acc[n][1][r]);
+                        const float e2 = __builtin_amdgcn_exp2f(acc[n][2][r]), e3 = __builtin_amdgcn_exp2f(acc[n][3][r]);
+                        const float ig = __builtin_amdgcn_rcpf(1.0f + e0), fg = __builtin_amdgcn_rcpf(1.0f + e1);
+                        const float t2 = __builtin_amdgcn_rcpf(e2 + 1.0f), og = __builtin_amdgcn_rcpf(1.0f + e3);
+                        const float gg = __builtin_fmaf(-2.0f, t2, 1.0f);
+                        const float cv = __builtin_fmaf(fg, prev, ig * gg);
+                        cst[n][r >> 2][r & 3] = cv;
+                        float t5 = __builtin_amdgcn_exp2f(P2L2E * cv);
+                        t5 = __builtin_amdgcn_rcpf(t5 + 1.0f);
+                        hv[r] = og * __builtin_fmaf(-2.0f, t5, 1.0f);
+                        if constexpr (SAVE) { sv[0][r] = ig; sv[1][r] = fg; sv[2][r] = gg; sv[3][r] = og; sv[4][r] = cv; }
+                    } else {
+                        const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][0][r]));
+                        const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][1][r]));
+                        float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[n][3][r], acc[n][2][r]));
+                        t2 = __builtin_amdgcn_rcpf(t2 + 1.0f);
+                        const float ng = __builtin_fmaf(-2.0f, t2, 1.0f);
+                        const float h = __builtin_fmaf(zg, prev, (1.0f - zg) * ng);
+                        cst[n][r >> 2][r & 3] = h;
+                        hv[r] = h;
+                        if constexpr (SAVE) { sv[0][r] = rg; sv[1][r] = zg; sv[2][r] = ng; sv[3][r] = acc[n][3][r] * (1.0f / P2L2E); sv[4][r] = h; }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4 *)(stp[n] + (size_t)u * 1024 + 4 * q) = cst[n][q];
+                bf16x8 h0, h1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { h0[j] = (__bf16)hv[j]; h1[j] = (__bf16)hv[8 + j]; }
+                // h_t goes to the layer output now and from there into LDS once every wave is done with h_{t-1}
+                op[n][(2 * u) * 64] = h0;
+                op[n][(2 * u + 1) * 64] = h1;
+                if constexpr (SAVE) {
+                    float *svb = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bbs[n]) * NU + u) * 5) * 1024 + lane * 16;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(f32x4 *)(svb + k * 1024 + 4 * q) = f32x4{sv[k][4 * q], sv[k][4 * q + 1], sv[k][4 * q + 2], sv[k][4 * q + 3]};
                 }
             }
-            bf16x8 h0, h1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { h0[j] = (__bf16)hv[j]; h1[j] = (__bf16)hv[8 + j]; }
-            // the other buffer was last read in step s - 1, which every wave has left (barrier below)
-            hnext[(2 * u) * 64] = h0;
-            hnext[(2 * u + 1) * 64] = h1;
-            __builtin_nontemporal_store(h0, op + (2 * u) * 64);
-            __builtin_nontemporal_store(h1, op + (2 * u + 1) * 64);
-            if constexpr (SAVE) {
-                float *svb = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bb) * NU + u) * 5) * 1024 + lane * 16;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(f32x4 *)(svb + k * 1024 + 4 * q) = f32x4{sv[k][4 * q], sv[k][4 * q + 1], sv[k][4 * q + 2], sv[k][4 * q + 3]};
-            }
-            // rotate the state registers: the next block of this wave becomes state[0]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float first = state[0][r];
-#pragma unroll
-                for (int k = 0; k + 1 < NUW; ++k) state[k][r] = state[k + 1][r];
-                state[NUW - 1][r] = first;
-            }
         }
-        __syncthreads();   // h_t complete in LDS; every wave is done with h_{t-1}
+        __syncthreads();   // every wave is done with h_{t-1} (and this wave's stores of h_t have been issued and waited for)
+        // this wave's part of h_t: back from the layer output (its own stores, L2) into the LDS buffer
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+            for (int f = 0; f < 2 * NUW; ++f) {
+                const int fr = 2 * wave * NUW + f;
+                ((bf16x8 *)hlds)[(size_t)(n * KH + fr) * 64 + lane] = op[n][fr * 64];
+            }
+        __syncthreads();   // h_t complete in LDS
     }
 }
 
 template <int NUW, bool L0, bool GRU, bool SAVE>
 static int tdw_launch(const TdLayerParams &p, int kx0, hipStream_t stream) {
-    const size_t shm = (size_t)2 * (8 * NUW) * TD_FRAG_BYTES;
+    const size_t shm = (size_t)TDW_NB * (8 * NUW) * TD_FRAG_BYTES;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         attr_done = true;
     }
-    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>), dim3(p.nbb * p.dirs), dim3(256), shm, stream, p, kx0);
+    const int tiles = td_cdiv(p.nbb, TDW_NB);
+    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>), dim3(tiles * p.dirs), dim3(256), shm, stream, p, kx0);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
@@ -227,6 +274,10 @@ static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, 
 
 // nu: padded 32-unit blocks (12, 16, 24 or 32); kx0: layer-0 input k-steps
 int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
+    if (!p.state) {
+        td_set_error("wide recurrent layer: no state scratch");
+        return TD_ERR_INVALID;
+    }
     if (!layer0 && p.in_frags != p.dirs * 2 * nu) {
         td_set_error("wide recurrent layer: %d input fragments, expected %d", p.in_frags, p.dirs * 2 * nu);
         return TD_ERR_INVALID;
