@@ -13,7 +13,17 @@ extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
 
 // wide layers (rnn_wide.hip) keep the recurrent state of a step in a scratch region, one per direction
 static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
-    return g.nu > 8 ? (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.nu * 1024 * sizeof(float) : 0;
+    return g.nu % 4 == 0 ? (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.nu * 1024 * sizeof(float) : 0;
+}
+
+// Which recurrent-layer kernel runs a layer.  rnn_layer.h (a wave = a batch block, all units) needs
+// ceil(nbb / 4) * dirs >= ~128 workgroups to fill the chip, i.e. thousands of sequences; below that -- the
+// reference's own batch sizes: 32 for training, 100 for sampling -- rnn_wide.hip's decomposition (the four waves of
+// a workgroup split the units of one batch block) puts 4x the waves on a batch block and cuts the per-step
+// latency accordingly.  Always rnn_wide.hip above H = 256.
+static bool td_use_wide(const TdRnnGeom &g, int nbb) {
+    if (g.nu > 8) return true;
+    return g.nu % 4 == 0 && td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs < 128;
 }
 
 // workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]
@@ -467,7 +477,7 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
         p.state = state;
         p.state_dir_stride = td_state_dir_bytes(g, batch) / sizeof(float);
         const int kxsel = l == 0 ? g.kx0 : g.dirs;
-        if (g.nu > 8) {
+        if (td_use_wide(g, nbb)) {
             const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
             rc = td_launch_layer_wide(cfg->gru, saves ? 1 : 0, g.nu, p, l == 0, g.kx0, stream);
             td_profile_end(slot, stream);

@@ -26,11 +26,10 @@ __device__ __forceinline__ void tdw_static_for(F &&f) {
     }
 }
 
-#define TDW_NB 2   // batch blocks (of 32 sequences) per workgroup: every weight fragment feeds TDW_NB MFMAs
-
-template <int NUW, bool L0, bool GRU, bool SAVE>
+// NB: batch blocks (of 32 sequences) per workgroup, every weight fragment feeds NB MFMAs.  2 when the batch fills
+// the chip that way, 1 for small batches (twice the workgroups).
+template <int NUW, int NB, bool L0, bool GRU, bool SAVE>
 __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
-    constexpr int NB = TDW_NB;
     constexpr int NG = GRU ? 3 : 4, NU = 4 * NUW, KH = 2 * NU, CH = 4 * NG;   // CH: weight fragments per chunk
     extern __shared__ __attribute__((aligned(16))) char hlds[];                 // [NB][KH] fragments: h_{t-1}
     const int tid = threadIdx.x, lane = tid & 63;
@@ -247,32 +246,39 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
     }
 }
 
-template <int NUW, bool L0, bool GRU, bool SAVE>
+template <int NUW, int NB, bool L0, bool GRU, bool SAVE>
 static int tdw_launch(const TdLayerParams &p, int kx0, hipStream_t stream) {
-    const size_t shm = (size_t)TDW_NB * (8 * NUW) * TD_FRAG_BYTES;
+    const size_t shm = (size_t)NB * (8 * NUW) * TD_FRAG_BYTES;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>,
+        TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         attr_done = true;
     }
-    const int tiles = td_cdiv(p.nbb, TDW_NB);
-    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, L0, GRU, SAVE>), dim3(tiles * p.dirs), dim3(256), shm, stream, p, kx0);
+    const int tiles = td_cdiv(p.nbb, NB);
+    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE>), dim3(tiles * p.dirs), dim3(256), shm, stream, p, kx0);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
 
-template <int NUW>
-static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
+template <int NUW, int NB>
+static int tdw_dispatch2(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
     if (layer0) {
-        if (!gru) return save ? tdw_launch<NUW, true, false, true>(p, kx0, stream) : tdw_launch<NUW, true, false, false>(p, kx0, stream);
-        return save ? tdw_launch<NUW, true, true, true>(p, kx0, stream) : tdw_launch<NUW, true, true, false>(p, kx0, stream);
+        if (!gru) return save ? tdw_launch<NUW, NB, true, false, true>(p, kx0, stream) : tdw_launch<NUW, NB, true, false, false>(p, kx0, stream);
+        return save ? tdw_launch<NUW, NB, true, true, true>(p, kx0, stream) : tdw_launch<NUW, NB, true, true, false>(p, kx0, stream);
     }
-    if (!gru) return save ? tdw_launch<NUW, false, false, true>(p, kx0, stream) : tdw_launch<NUW, false, false, false>(p, kx0, stream);
-    return save ? tdw_launch<NUW, false, true, true>(p, kx0, stream) : tdw_launch<NUW, false, true, false>(p, kx0, stream);
+    if (!gru) return save ? tdw_launch<NUW, NB, false, false, true>(p, kx0, stream) : tdw_launch<NUW, NB, false, false, false>(p, kx0, stream);
+    return save ? tdw_launch<NUW, NB, false, true, true>(p, kx0, stream) : tdw_launch<NUW, NB, false, true, false>(p, kx0, stream);
 }
 
-// nu: padded 32-unit blocks (12, 16, 24 or 32); kx0: layer-0 input k-steps
+template <int NUW>
+static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
+    // one workgroup per CU at a time: with fewer single-block workgroups than CUs, pairing blocks would idle CUs
+    if (p.nbb * p.dirs > 256) return tdw_dispatch2<NUW, 2>(gru, save, p, layer0, kx0, stream);
+    return tdw_dispatch2<NUW, 1>(gru, save, p, layer0, kx0, stream);
+}
+
+// nu: padded 32-unit blocks (4, 8, 12, 16, 24 or 32); kx0: layer-0 input k-steps
 int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
     if (!p.state) {
         td_set_error("wide recurrent layer: no state scratch");
@@ -283,6 +289,8 @@ int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool
         return TD_ERR_INVALID;
     }
     switch (nu) {
+        case 4: return tdw_dispatch<1>(gru, save, p, layer0, kx0, stream);   // small batches at H <= 256: td_use_wide()
+        case 8: return tdw_dispatch<2>(gru, save, p, layer0, kx0, stream);
         case 12: return tdw_dispatch<3>(gru, save, p, layer0, kx0, stream);
         case 16: return tdw_dispatch<4>(gru, save, p, layer0, kx0, stream);
         case 24: return tdw_dispatch<6>(gru, save, p, layer0, kx0, stream);

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--timesteps", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--train-batch", type=int, default=0,
+                    help="also time the training step (BASELINE.json configs[4]: wide-hidden BRNN at a large batch), "
+                         "eICU-shaped, this many sequences per optimizer step on this GPU")
     args = ap.parse_args()
     from timediff_amd import _lib
     from timediff_amd.ops import DenoiserKernels, DiffusionKernels, SamplerKernels
@@ -74,6 +77,12 @@ def main():
         }), flush=True)
         del den, sampler, diff, x, y, out
         torch.cuda.empty_cache()
+        if args.train_batch:
+            from bench import EICU, train_probe
+            r = train_probe(dev, EICU, 272, H, N, 1000, args.train_batch, 1, 3, 1)
+            r["denoiser_tflops_fwd_bwd"] = 3 * denoiser_flops_per_seq(14, H, N, D, 272) * r["sequences_per_s"] / 1e12
+            print(json.dumps({"train": r}), flush=True)
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
