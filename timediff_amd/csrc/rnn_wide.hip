@@ -31,7 +31,11 @@ __device__ __forceinline__ void tdw_static_for(F &&f) {
 template <int NUW, int NB, bool L0, bool GRU, bool SAVE>
 __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
     constexpr int NG = GRU ? 3 : 4, NU = 4 * NUW, KH = 2 * NU, CH = 4 * NG;   // CH: weight fragments per chunk
-    extern __shared__ __attribute__((aligned(16))) char hlds[];                 // [NB][KH] fragments: h_{t-1}
+    // h_{t-1} as B fragments, [NB][KH] KiB.  Double buffered when two copies fit (one barrier per step, h_t written
+    // straight into the other buffer); otherwise single buffered: h_t goes to the layer output first and is copied
+    // back into LDS between two barriers.
+    constexpr bool DBUF = NB * NUW <= 8;
+    extern __shared__ __attribute__((aligned(16))) char hlds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = p.dirs == 2 ? (blockIdx.x & 1) : 0;
@@ -45,16 +49,17 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
     const int XFR0 = L0 ? 2 * kx0 : 0;                   // first layer: hi + lo fragments
     const int FU = 4 + (KH + (L0 ? XFR0 : KXF)) * NG;    // weight fragments per unit block
 
-    for (int i = tid; i < NB * KH * 64; i += 256) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0
+    for (int i = tid; i < NB * KH * 64; i += 256) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0 (buffer 0)
     __syncthreads();
 
     bf16x8 ones = {};
     if (lane < 32) { ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f; }
     const bf16x8 *wdir = (const bf16x8 *)(p.wpacked + (size_t)dir * p.dir_stride) + lane;
-    const bf16x8 *hl = (const bf16x8 *)hlds + lane;
 
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
+        const bf16x8 *hl = (const bf16x8 *)(hlds + (DBUF ? (size_t)(s & 1) * NB * KH * TD_FRAG_BYTES : 0)) + lane;
+        bf16x8 *hnext = (bf16x8 *)(hlds + (size_t)((s + 1) & 1) * NB * KH * TD_FRAG_BYTES) + lane;   // DBUF only
         const bf16x8 *xp[NB];
         bf16x8 *op[NB];
         float *stp[NB];
@@ -222,8 +227,16 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { h0[j] = (__bf16)hv[j]; h1[j] = (__bf16)hv[8 + j]; }
                 // h_t goes to the layer output now and from there into LDS once every wave is done with h_{t-1}
-                op[n][(2 * u) * 64] = h0;
-                op[n][(2 * u + 1) * 64] = h1;
+                if constexpr (DBUF) {
+                    // the other buffer was last read in step s - 1, which every wave has left
+                    hnext[(n * KH + 2 * u) * 64] = h0;
+                    hnext[(n * KH + 2 * u + 1) * 64] = h1;
+                    __builtin_nontemporal_store(h0, op[n] + (2 * u) * 64);
+                    __builtin_nontemporal_store(h1, op[n] + (2 * u + 1) * 64);
+                } else {
+                    op[n][(2 * u) * 64] = h0;
+                    op[n][(2 * u + 1) * 64] = h1;
+                }
                 if constexpr (SAVE) {
                     float *svb = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bbs[n]) * NU + u) * 5) * 1024 + lane * 16;
 #pragma unroll
@@ -234,21 +247,23 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
                 }
             }
         }
-        __syncthreads();   // every wave is done with h_{t-1} (and this wave's stores of h_t have been issued and waited for)
-        // this wave's part of h_t: back from the layer output (its own stores, L2) into the LDS buffer
+        if constexpr (!DBUF) {
+            __syncthreads();   // every wave is done with h_{t-1} (and this wave's stores of h_t have been issued and waited for)
+            // this wave's part of h_t: back from the layer output (its own stores, L2) into the LDS buffer
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
-            for (int f = 0; f < 2 * NUW; ++f) {
-                const int fr = 2 * wave * NUW + f;
-                ((bf16x8 *)hlds)[(size_t)(n * KH + fr) * 64 + lane] = op[n][fr * 64];
-            }
+            for (int n = 0; n < NB; ++n)
+                for (int f = 0; f < 2 * NUW; ++f) {
+                    const int fr = 2 * wave * NUW + f;
+                    ((bf16x8 *)hlds)[(size_t)(n * KH + fr) * 64 + lane] = op[n][fr * 64];
+                }
+        }
         __syncthreads();   // h_t complete in LDS
     }
 }
 
 template <int NUW, int NB, bool L0, bool GRU, bool SAVE>
 static int tdw_launch(const TdLayerParams &p, int kx0, hipStream_t stream) {
-    const size_t shm = (size_t)NB * (8 * NUW) * TD_FRAG_BYTES;
+    const size_t shm = (size_t)(NB * NUW <= 8 ? 2 : 1) * NB * (8 * NUW) * TD_FRAG_BYTES;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE>,
