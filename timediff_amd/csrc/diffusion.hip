@@ -254,8 +254,10 @@ __global__ __launch_bounds__(256) void td_mixed_loss_kernel(td_diffusion_config 
         float term = 0.f, prior = 0.f;
         int off = 0;
         // q(x_t | x_{t-1}) in log space (:255-262) takes two values per class count: the current class or not
+        // ... and so do the true posterior's q(x_{t-1} | x_0) term and the prior KL (x_0 is exactly one-hot): computed
+        // once per class count instead of once per class -- the same expressions on the same inputs, bit for bit
         int lastK = -1;
-        float logK = 0.f, w_hit = 0.f, w_miss = 0.f;
+        float logK = 0.f, w_hit = 0.f, w_miss = 0.f, evt_hit = 0.f, evt_miss = 0.f, prior_hit = 0.f, prior_miss = 0.f;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
             if (K != lastK) {
@@ -263,6 +265,11 @@ __global__ __launch_bounds__(256) void td_mixed_loss_kernel(td_diffusion_config 
                 logK = logf((float)K);
                 w_hit = td_log_add_exp(0.f + la, l1ma - logK);
                 w_miss = td_log_add_exp(TD_LOG_1E30 + la, l1ma - logK);
+                evt_hit = tb == 0 ? 0.f : td_log_add_exp(0.f + lca, l1mca - logK);
+                evt_miss = tb == 0 ? TD_LOG_1E30 : td_log_add_exp(TD_LOG_1E30 + lca, l1mca - logK);
+                const float lq_hit = td_log_add_exp(0.f + lcaT, l1mcaT - logK), lq_miss = td_log_add_exp(TD_LOG_1E30 + lcaT, l1mcaT - logK);
+                prior_hit = expf(lq_hit) * (lq_hit + logK);                                // :330-339
+                prior_miss = expf(lq_miss) * (lq_miss + logK);
             }
             const float *zp = mo + ((size_t)b * C_io + c.n_num + off) * L + l;
             const int x0 = x0_idx[((size_t)b * c.n_cat + v) * L + l], xt = xt_idx[((size_t)b * c.n_cat + v) * L + l];
@@ -275,33 +282,33 @@ __global__ __launch_bounds__(256) void td_mixed_loss_kernel(td_diffusion_config 
             }
             float se = 0.f;
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) se += k < K ? expf(lx0h[k] - m) : 0.f;
+            for (int k = 0; k < TD_KMAX; ++k)
+                if (k < K) se += expf(lx0h[k] - m);
             const float lse = m + logf(se);
             float mt = -INFINITY, mm = -INFINITY;
 #pragma unroll
             for (int k = 0; k < TD_KMAX; ++k) {
                 if (k < K) {
                     lx0h[k] -= lse;                                                        // :274-281
-                    const float lx0 = k == x0 ? 0.f : TD_LOG_1E30;
-                    const float w = td_log_add_exp((k == xt ? 0.f : TD_LOG_1E30) + la, l1ma - logK);
-                    const float evt = tb == 0 ? lx0 : td_log_add_exp(lx0 + lca, l1mca - logK);
+                    const float w = k == xt ? w_hit : w_miss;
+                    const float evt = k == x0 ? evt_hit : evt_miss;
                     const float evm = tb == 0 ? lx0h[k] : td_log_add_exp(lx0h[k] + lca, l1mca - logK);
                     ut[k] = evt + w;
                     um[k] = evm + w;
                     mt = fmaxf(mt, ut[k]);
                     mm = fmaxf(mm, um[k]);
-                    const float lq = td_log_add_exp(lx0 + lcaT, l1mcaT - logK);
-                    prior += expf(lq) * (lq + logK);                                       // :330-339
+                    prior += k == x0 ? prior_hit : prior_miss;
                 } else {
                     ut[k] = -INFINITY; um[k] = -INFINITY;
                 }
             }
             float st = 0.f, sm = 0.f;
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) {
-                st += k < K ? expf(ut[k] - mt) : 0.f;
-                sm += k < K ? expf(um[k] - mm) : 0.f;
-            }
+            for (int k = 0; k < TD_KMAX; ++k)
+                if (k < K) {
+                    st += expf(ut[k] - mt);
+                    sm += expf(um[k] - mm);
+                }
             const float lset = mt + logf(st), lsem = mm + logf(sm);  // direct per-slice logsumexp (vs :32-42)
             float tgt_sum = 0.f, gp = 0.f;
             float gk[TD_KMAX];

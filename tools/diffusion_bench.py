@@ -61,7 +61,15 @@ def main():
     rec("td_build_input_kernel", timed(lambda: diff.build_input(z, idx)), B * L * (4 * n_num + n_cat + 4 * C_io))
     # head: last layer's fragments in, (B, C_io, L) out  -- timed through a whole denoiser forward minus the layers is not
     # separable here; the rocprof kernel stats of bench.py give its duration (profiles/README.md)
-    print(json.dumps(dict(batch=B, seq_len=L, hbm_peak_gbps=HBM_PEAK, kernels=res)))
+    # what plain streaming reaches on this box (context for the fractions above): a 2 GiB device copy and a 2 GiB read
+    a = torch.empty(1 << 29, dtype=torch.float32, device=dev).normal_()
+    c = torch.empty_like(a)
+    ref = {}
+    secs = timed(lambda: c.copy_(a), reps=5)
+    ref["copy_2GiB_read_plus_write"] = dict(ms=secs * 1e3, gbps=2 * a.numel() * 4 / secs / 1e9)
+    secs = timed(lambda: a.sum(), reps=5)
+    ref["sum_2GiB_read_only"] = dict(ms=secs * 1e3, gbps=a.numel() * 4 / secs / 1e9)
+    print(json.dumps(dict(batch=B, seq_len=L, hbm_peak_gbps=HBM_PEAK, kernels=res, streaming_reference=ref)))
 
 
 if __name__ == "__main__":
