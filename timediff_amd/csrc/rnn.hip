@@ -4,6 +4,7 @@
 #include "rnn_geom.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
     TdRnnGeom g;
@@ -17,13 +18,19 @@ static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
 }
 
 // Which recurrent-layer kernel runs a layer.  rnn_layer.h (a wave = a batch block, all units) needs
-// ceil(nbb / 4) * dirs >= ~128 workgroups to fill the chip, i.e. thousands of sequences; below that -- the
+// ceil(nbb / 4) * dirs > 128 workgroups to fill the chip, i.e. thousands of sequences; below that -- the
 // reference's own batch sizes: 32 for training, 100 for sampling -- rnn_wide.hip's decomposition (the four waves of
 // a workgroup split the units of one batch block) puts 4x the waves on a batch block and cuts the per-step
 // latency accordingly.  Always rnn_wide.hip above H = 256.
 static bool td_use_wide(const TdRnnGeom &g, int nbb) {
     if (g.nu > 8) return true;
-    return g.nu % 4 == 0 && td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs < 128;
+    // A/B switch for measurements: TIMEDIFF_LAYER_KERNEL=batch forces rnn_layer.h, =units forces rnn_wide.hip
+    static const char *force = getenv("TIMEDIFF_LAYER_KERNEL");
+    if (force && force[0] == 'b') return false;
+    if (force && force[0] == 'u') return g.nu % 4 == 0;
+    // measured at H = 256: the unit-split kernel wins while its workgroups (one or two batch
+    // blocks each) fit the chip in one round, i.e. up to 8192 sequences bidirectional
+    return g.nu % 4 == 0 && td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs <= 128;
 }
 
 // workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]
