@@ -8,6 +8,7 @@ Extra flags (not in the reference): --num_samples, --sample_batch_size, --synthe
 tensor of the dataset's shape when the credentialed data is not available).
 """
 import argparse
+import os
 
 import numpy as np
 import torch
@@ -78,8 +79,17 @@ def collect_samples(model, num_samples, batch_size=20, min=None, max=None, posit
     model.eval()
     samples_list = []
     if not positive_only:
-        for _ in range(num_samples // batch_size):
-            samples_list.append(model.sample(batch_size=batch_size))
+        # The reference runs num_samples // batch_size chains of batch_size patients one after the other (200 x 100 by
+        # default).  Chains never interact (mixed_diffusion.py:437-446 has no cross-batch operation), so the same
+        # patients are drawn in as few chains as fit the GPU: at the reference's batch of 100 a chain keeps 4 of the
+        # MI355X's 256 CUs busy (11 sequences/s), at 16 384 all of them (480 sequences/s).
+        total = (num_samples // batch_size) * batch_size
+        chunk = int(os.environ.get("TIMEDIFF_SAMPLE_CHUNK", "16384"))
+        done = 0
+        while done < total:
+            n = builtins_min(chunk, total - done)
+            samples_list.append(model.sample(batch_size=n))
+            done += n
     else:
         print("*** COLLECT POSITIVE SAMPLES ***")
         collected = 0

@@ -161,3 +161,28 @@ def test_layer_slices_and_uncovered_ranges():
     assert uncovered_ranges(n, [sl[2], sl[0], sl[1]]) == [(0, sl[0][0]), (sl[2][1], n)]
     assert uncovered_ranges(n, []) == [(0, n)]
     assert uncovered_ranges(10, [(0, 4), (4, 10)]) == []
+
+
+def test_collect_samples_fuses_chains(monkeypatch):
+    """collect_samples (etdiff_train.py:150-166): num_samples // batch_size chains of batch_size patients, drawn in
+    GPU-filling chunks; same count, order of concatenation and de-normalisation as the reference."""
+    import etdiff_train as cli
+
+    class Fake:
+        def __init__(self):
+            self.calls = []
+
+        def eval(self):
+            return self
+
+        def sample(self, batch_size):
+            self.calls.append(batch_size)
+            return torch.full((batch_size, 3, 4), 0.5)
+
+    m = Fake()
+    out = cli.collect_samples(m, 1050, batch_size=100, min=np.zeros((1, 3, 1)), max=np.full((1, 3, 1), 2.0))
+    assert out.shape == (1000, 3, 4) and m.calls == [1000] and np.allclose(out, 1.0)
+    monkeypatch.setenv("TIMEDIFF_SAMPLE_CHUNK", "300")
+    m = Fake()
+    out = cli.collect_samples(m, 1000, batch_size=100)
+    assert out.shape == (1000, 3, 4) and m.calls == [300, 300, 300, 100]
