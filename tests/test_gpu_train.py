@@ -187,7 +187,12 @@ def _run_dp(tmp_path, overlap, port):
         p.start()
     for p in procs:
         p.join(110)
-        assert p.exitcode == 0, f"data-parallel rank exited with {p.exitcode}"
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.exitcode is None:      # never leave a rank behind on the GPU
+            p.kill()
+            p.join(10)
+    assert codes == [0, 0], f"data-parallel ranks exited with {codes} (None = still running after 110 s, killed)"
     return torch.load(out, weights_only=True)
 
 

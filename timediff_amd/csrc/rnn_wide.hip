@@ -26,15 +26,22 @@ __device__ __forceinline__ void tdw_static_for(F &&f) {
     }
 }
 
+#ifndef TDW_EIGHT_WAVES_MAX_WG
+#define TDW_EIGHT_WAVES_MAX_WG 32   // up to this many workgroups (512 sequences bidirectional) the small-batch variant runs eight waves each
+#endif
+
 // NB: batch blocks (of 32 sequences) per workgroup, every weight fragment feeds NB MFMAs.  2 when the batch fills
 // the chip that way, 1 for small batches (twice the workgroups).
-template <int NUW, int NB, bool L0, bool GRU, bool SAVE>
-__global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
-    constexpr int NG = GRU ? 3 : 4, NU = 4 * NUW, KH = 2 * NU, CH = 4 * NG;   // CH: weight fragments per chunk
+// WAVES: waves per workgroup = ways the unit blocks are split: 4 (one wave per SIMD), or 8 for small batches, where
+// only a few workgroups run and a second wave per SIMD hides the other's L2 latency.
+template <int NUW, int NB, bool L0, bool GRU, bool SAVE, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
+    constexpr int NG = GRU ? 3 : 4, NU = WAVES * NUW, KH = 2 * NU;
+    constexpr int KC = WAVES == 8 ? 2 : 4, CH = KC * NG;   // k-steps / weight fragments per pipeline chunk (256 registers per wave with eight waves)
     // h_{t-1} as B fragments, [NB][KH] KiB.  Double buffered when two copies fit (one barrier per step, h_t written
     // straight into the other buffer); otherwise single buffered: h_t goes to the layer output first and is copied
     // back into LDS between two barriers.
-    constexpr bool DBUF = NB * NUW <= 8;
+    constexpr bool DBUF = NB * NUW * WAVES <= 32;
     extern __shared__ __attribute__((aligned(16))) char hlds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
     const int XFR0 = L0 ? 2 * kx0 : 0;                   // first layer: hi + lo fragments
     const int FU = 4 + (KH + (L0 ? XFR0 : KXF)) * NG;    // weight fragments per unit block
 
-    for (int i = tid; i < NB * KH * 64; i += 256) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0 (buffer 0)
+    for (int i = tid; i < NB * KH * 64; i += 64 * WAVES) ((bf16x8 *)hlds)[i] = bf16x8{};   // h_{-1} = 0 (buffer 0)
     __syncthreads();
 
     bf16x8 ones = {};
@@ -93,32 +100,32 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[n][g][r] = 0.f;
 
-            // Two-chunk software pipeline over the weight stream after the bias fragments; a chunk = 4 k-steps =
+            // Two-chunk software pipeline over the weight stream after the bias fragments; a chunk = KC k-steps =
             // CH weight fragments + the B operands they meet (h_{t-1} from LDS, then the layer input from L2).
             // Straight-line bodies (no branch between a load and its use), so the compiler's counted vmcnt waits
             // let chunk c+1's loads stay in flight under chunk c's MFMAs.
-            bf16x8 A0[CH], A1[CH], B0[NB][4], B1[NB][4];
+            bf16x8 A0[CH], A1[CH], B0[NB][KC], B1[NB][KC];
             auto ldA = [&](int c, bf16x8(&A)[CH]) {
                 const bf16x8 *wp = wa + (size_t)(4 + c * CH) * 64;
 #pragma unroll
                 for (int j = 0; j < CH; ++j) A[j] = wp[j * 64];
             };
-            auto ldH = [&](int c, bf16x8(&B)[NB][4]) {
+            auto ldH = [&](int c, bf16x8(&B)[NB][KC]) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) B[n][k] = hl[(n * KH + 4 * c + k) * 64];
+                    for (int k = 0; k < KC; ++k) B[n][k] = hl[(n * KH + KC * c + k) * 64];
             };
-            auto ldX = [&](int c, bf16x8(&B)[NB][4]) {   // c counts from the first input chunk
+            auto ldX = [&](int c, bf16x8(&B)[NB][KC]) {   // c counts from the first input chunk
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) B[n][k] = xp[n][(4 * c + k) * 64];
+                    for (int k = 0; k < KC; ++k) B[n][k] = xp[n][(KC * c + k) * 64];
             };
-            auto mma = [&](auto recc, bf16x8(&A)[CH], bf16x8(&B)[NB][4]) {
+            auto mma = [&](auto recc, bf16x8(&A)[CH], bf16x8(&B)[NB][KC]) {
                 constexpr bool rec = decltype(recc)::value;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < KC; ++k)
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         // GRU n gate: the recurrent half accumulates apart (it is multiplied by r)
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
             };
             constexpr std::true_type REC{};
             constexpr std::false_type INP{};
-            const int NH = KH / 4, NX = KXF / 4;   // both even
+            const int NH = KH / KC, NX = KXF / KC;   // both even
             // PIN: the machine scheduler otherwise sinks each load next to its MFMA to save registers, which turns the
             // pipeline into load -> wait -> 2 MFMAs per fragment
 #define TDW_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -261,36 +268,42 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_wide_kernel(TdLayerParams
     }
 }
 
-template <int NUW, int NB, bool L0, bool GRU, bool SAVE>
+template <int NUW, int NB, bool L0, bool GRU, bool SAVE, int WAVES = 4>
 static int tdw_launch(const TdLayerParams &p, int kx0, hipStream_t stream) {
-    const size_t shm = (size_t)(NB * NUW <= 8 ? 2 : 1) * NB * (8 * NUW) * TD_FRAG_BYTES;
+    const size_t shm = (size_t)(NB * NUW * WAVES <= 32 ? 2 : 1) * NB * (2 * WAVES * NUW) * TD_FRAG_BYTES;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE>,
+        TD_HIP(hipFuncSetAttribute((const void *)td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE, WAVES>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         attr_done = true;
     }
     const int tiles = td_cdiv(p.nbb, NB);
-    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE>), dim3(tiles * p.dirs), dim3(256), shm, stream, p, kx0);
+    hipLaunchKernelGGL((td_rnn_layer_wide_kernel<NUW, NB, L0, GRU, SAVE, WAVES>), dim3(tiles * p.dirs), dim3(64 * WAVES), shm,
+                       stream, p, kx0);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
 
-template <int NUW, int NB>
+template <int NUW, int NB, int WAVES>
 static int tdw_dispatch2(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
     if (layer0) {
-        if (!gru) return save ? tdw_launch<NUW, NB, true, false, true>(p, kx0, stream) : tdw_launch<NUW, NB, true, false, false>(p, kx0, stream);
-        return save ? tdw_launch<NUW, NB, true, true, true>(p, kx0, stream) : tdw_launch<NUW, NB, true, true, false>(p, kx0, stream);
+        if (!gru) return save ? tdw_launch<NUW, NB, true, false, true, WAVES>(p, kx0, stream) : tdw_launch<NUW, NB, true, false, false, WAVES>(p, kx0, stream);
+        return save ? tdw_launch<NUW, NB, true, true, true, WAVES>(p, kx0, stream) : tdw_launch<NUW, NB, true, true, false, WAVES>(p, kx0, stream);
     }
-    if (!gru) return save ? tdw_launch<NUW, NB, false, false, true>(p, kx0, stream) : tdw_launch<NUW, NB, false, false, false>(p, kx0, stream);
-    return save ? tdw_launch<NUW, NB, false, true, true>(p, kx0, stream) : tdw_launch<NUW, NB, false, true, false>(p, kx0, stream);
+    if (!gru) return save ? tdw_launch<NUW, NB, false, false, true, WAVES>(p, kx0, stream) : tdw_launch<NUW, NB, false, false, false, WAVES>(p, kx0, stream);
+    return save ? tdw_launch<NUW, NB, false, true, true, WAVES>(p, kx0, stream) : tdw_launch<NUW, NB, false, true, false, WAVES>(p, kx0, stream);
 }
 
+// NUW: unit blocks per wave with four waves
 template <int NUW>
 static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
     // one workgroup per CU at a time: with fewer single-block workgroups than CUs, pairing blocks would idle CUs
-    if (p.nbb * p.dirs > 256) return tdw_dispatch2<NUW, 2>(gru, save, p, layer0, kx0, stream);
-    return tdw_dispatch2<NUW, 1>(gru, save, p, layer0, kx0, stream);
+    if (p.nbb * p.dirs > 256) return tdw_dispatch2<NUW, 2, 4>(gru, save, p, layer0, kx0, stream);
+    // few workgroups (the reference's batch sizes): eight waves, two per SIMD, each with half the unit blocks
+    if constexpr (NUW % 2 == 0) {
+        if (p.nbb * p.dirs <= TDW_EIGHT_WAVES_MAX_WG) return tdw_dispatch2<NUW / 2, 1, 8>(gru, save, p, layer0, kx0, stream);
+    }
+    return tdw_dispatch2<NUW, 1, 4>(gru, save, p, layer0, kx0, stream);
 }
 
 // nu: padded 32-unit blocks (4, 8, 12, 16, 24 or 32); kx0: layer-0 input k-steps

@@ -46,6 +46,10 @@ class TimeSeriesDataset(Dataset):
     def __getitem__(self, idx):
         return self.data[idx].clone()
 
+    def __getitems__(self, indices):
+        """Batched fetch (torch's DataLoader calls this when present): one gather instead of len(indices) clones."""
+        return self.data[torch.as_tensor(indices)]
+
     @property
     def channels(self):
         return self.data.shape[1]
@@ -67,6 +71,7 @@ class TensorSeriesDataset(Dataset):
 
     __len__ = TimeSeriesDataset.__len__
     __getitem__ = TimeSeriesDataset.__getitem__
+    __getitems__ = TimeSeriesDataset.__getitems__
     channels = TimeSeriesDataset.channels
     seq_length = TimeSeriesDataset.seq_length
 

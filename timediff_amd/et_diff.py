@@ -38,6 +38,11 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _batch_passthrough(batch):
+    """collate_fn for datasets whose __getitems__ already returns the (B, C, L) batch tensor."""
+    return batch
+
+
 def _flatten_params_(module):
     """Re-points every parameter of `module` into one contiguous fp32 buffer; returns (flat, params)."""
     params = [p for p in module.parameters()]
@@ -124,8 +129,11 @@ class ETDiff(nn.Module):
         sampler = None
         if self.world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(dataset, self.world, self.rank, shuffle=True, seed=run_id)
+        # no loader workers: the dataset is one in-memory tensor (a batch is one gather: TimeSeriesDataset.__getitems__), and a worker would be forked from a process that has
+        # already initialised HIP (a forked child can inherit a runtime lock that is held and never released: a rare hang)
         dl = DataLoader(dataset, batch_size=self.local_batch, shuffle=sampler is None, sampler=sampler, pin_memory=True,
-                        num_workers=1, drop_last=self.world > 1)
+                        num_workers=0, drop_last=self.world > 1,
+                        collate_fn=_batch_passthrough if hasattr(dataset, "__getitems__") else None)
         self.dl = cycle(dl)
 
         # flat buffers: weights, gradients, Adam moments, EMA weights
