@@ -15,8 +15,10 @@ def dev():
 
 def _dp_worker(rank, world, port, overlap, out_path):
     """One data-parallel rank (both ranks share GPU 0; gloo moves the CUDA gradient slices)."""
+    import faulthandler
     import os
     import sys
+    faulthandler.dump_traceback_later(90, exit=True)   # a stuck rank reports where and ends itself
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), TIMEDIFF_DIST_BACKEND="gloo", TIMEDIFF_DP_OVERLAP=str(overlap),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
