@@ -1,17 +1,21 @@
-// Wide hidden sizes (256 < H <= 1024: BASELINE.json configs[3], [4]) of the recurrent layer and the head.
+// The unit-split recurrent layer: wide hidden sizes (256 < H <= 1024: BASELINE.json configs[3], [4]) and small
+// batches at any width that is a multiple of 128 (rnn.hip: td_use_wide), plus the head for wide layers.
 //
 // Above H = 256 the state of 32 sequences (cell state fp32 + h as B fragments) no longer fits one wave's
-// registers, so the decomposition of rnn_layer.h turns by 90 degrees: a workgroup (4 waves, one per SIMD)
-// owns TDW_NB = 2 batch blocks of 32 sequences for all L steps and splits the hidden units: wave w owns the NUW
-// 32-unit blocks w*NUW .. w*NUW+NUW-1, for both batch blocks, so a weight fragment fetched from L2 feeds two
-// MFMAs.  The fp32 recurrent state of a block is kept in L2/HBM between steps (read a block of MFMAs ahead of its
-// use, 8 H bytes per sequence and step: nothing next to the weight stream), which leaves the registers to the
-// second set of accumulators.  h_{t-1} of all units is the B operand of every wave's recurrent k-steps and lives
-// in LDS (2 KH KiB <= 128 KiB, single buffered: h_t goes to the layer output first and is copied back into LDS
-// between two barriers).  The weight fragments are the same packed stream rnn_layer.h reads ([unit block][bias | W_hh k-steps |
-// W_ih k-steps][gate], td_pack_weights_kernel); each wave streams its own blocks' fragments L2 -> registers
-// through a two-chunk software pipeline (a chunk = 4 k-steps = 4*NG fragments).  The layer's input fragments
-// are read from L2/HBM as B operands with the chunk that uses them.
+// registers, so the decomposition of rnn_layer.h turns by 90 degrees: a workgroup owns NB batch blocks of 32
+// sequences for all L steps and its WAVES waves split the hidden units: wave w owns the NUW 32-unit blocks
+// w*NUW .. w*NUW+NUW-1, for every batch block, so a weight fragment fetched from L2 feeds NB MFMAs.
+//   NB = 2, WAVES = 4   the batch fills the chip with two blocks per workgroup (more than 256 single-block workgroups)
+//   NB = 1, WAVES = 4   fewer workgroups than CUs: one block each
+//   NB = 1, WAVES = 8   at most 32 workgroups (the reference's batch sizes): a second wave per SIMD hides L2 latency
+// The fp32 recurrent state of a block lives in L2/HBM between steps (read under the block's last MFMAs, 8 H bytes
+// per sequence and step: nothing next to the weight stream), which leaves the registers to the accumulators and
+// the operand pipeline.  h_{t-1} of all units is the B operand of every wave's recurrent k-steps and lives in LDS
+// (NB * KH KiB; double buffered when two copies fit, else h_t goes to the layer output first and is copied back
+// between two barriers).  The weight fragments are the same packed stream rnn_layer.h reads ([unit block][bias |
+// W_hh k-steps | W_ih k-steps][gate], td_pack_weights_kernel); each wave streams its own blocks' fragments
+// L2 -> registers through a pinned two-chunk software pipeline (a chunk = KC k-steps = KC*NG fragments).  The
+// layer's input fragments are read from L2/HBM as B operands with the chunk that uses them.
 //
 // Gate math: the same instruction sequence as rnn_layer.h's gate_op (the accumulators arrive pre-multiplied
 // by the exp2 factors), so the oracle's bf16 emulation covers both kernels.
