@@ -1,0 +1,37 @@
+// Weight-gradient GEMMs through rocBLAS: d W (M x N, fp32, accumulated) += A (M x K, bf16) . B (N x K, bf16)^T is a plain
+// library GEMM (K = L * batch columns, up to hundreds of thousands), the one place on this path where a vendor GEMM
+// is the right tool; td_dw_gemm_kernel (rnn_train.hip) stays for the shapes that need its column remap (hidden
+// sizes that are not a multiple of 32, the first layer's few input channels).
+#include <rocblas/rocblas.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+static rocblas_handle g_blas = nullptr;
+
+// C[m][n] += sum_k A[m][k] B[n][k]; A, B row-major bf16 with k contiguous (lda, ldb), C row-major fp32 (ldc).
+// Returns TD_OK, or TD_ERR_UNSUPPORTED when the caller should fall back to its own kernel.
+int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
+                   hipStream_t stream) {
+    static const char *force = getenv("TIMEDIFF_DW_GEMM");   // =kernel: never use the library (measurements)
+    if (force && force[0] == 'k') return TD_ERR_UNSUPPORTED;
+    if (lda > 0x7fffffff || ldb > 0x7fffffff) return TD_ERR_UNSUPPORTED;
+    if (!g_blas) {
+        if (rocblas_create_handle(&g_blas) != rocblas_status_success) {
+            g_blas = nullptr;
+            return TD_ERR_UNSUPPORTED;
+        }
+    }
+    if (rocblas_set_stream(g_blas, stream) != rocblas_status_success) return TD_ERR_UNSUPPORTED;
+    const float one = 1.0f;
+    // column-major view: C' (N x M, ld ldc) = Bc^T (N x K) . Ac (K x M), Bc = B as (K x N, ld ldb), Ac = A as (K x M, ld lda)
+    rocblas_status st = rocblas_gemm_ex(g_blas, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, B,
+                                        rocblas_datatype_bf16_r, (rocblas_int)ldb, A, rocblas_datatype_bf16_r,
+                                        (rocblas_int)lda, &one, C, rocblas_datatype_f32_r, ldc, C, rocblas_datatype_f32_r, ldc,
+                                        rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+    if (st != rocblas_status_success) {
+        td_set_error("rocblas_gemm_ex failed with status %d (M=%d N=%d K=%d)", (int)st, M, N, K);
+        return TD_ERR_HIP;
+    }
+    return TD_OK;
+}

@@ -18,6 +18,9 @@ int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, i
 
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
                          char *const *acts, float *const *saves, float *state, hipStream_t stream);
+// gemm_lib.cpp (rocBLAS); TD_ERR_UNSUPPORTED: use td_dw_gemm_kernel
+int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
+                   hipStream_t stream);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
                 const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
 
@@ -662,6 +665,18 @@ __global__ __launch_bounds__(256) void td_dw_gemm_kernel(TdDwParams p) {
     }
 }
 
+// The library GEMM where the shape allows (no column remap: hidden a multiple of 32, not the first layer's padded
+// channels), the kernel above otherwise.
+static int td_dw_gemm(const TdDwParams &q, int nu, hipStream_t stream) {
+    if (q.hp == q.hv) {
+        const int rc = td_dw_gemm_lib(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, stream);
+        if (rc != TD_ERR_UNSUPPORTED) return rc;
+    }
+    hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 // d b[m] += sum_k A[m][k] (one wave per row), added to up to two destinations
 __global__ __launch_bounds__(256) void td_bias_reduce_kernel(const __bf16 *A, size_t lda, int M, size_t K, float *dst0, float *dst1) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -799,8 +814,8 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                 q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = H; q.K = (int)t.cols;
                 if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
                 else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
-                hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(g.nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
-                TD_LAUNCH_CHECK();
+                rc = td_dw_gemm(q, g.nu, stream);
+                if (rc != TD_OK) return rc;
                 // W_hh: h_{t-1} is this direction's own output one step earlier in its processing order
                 if (L > 1) {
                     const __bf16 *hpl = (const __bf16 *)(ws + t.plain[l + 1]) + (size_t)d * g.hpad * t.cols;
@@ -809,8 +824,8 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                     q.B = d == 0 ? hpl : hpl + t.Bp;
                     q.C = gw[1] + (size_t)gate * H * H; q.ldc = H; q.K = (int)(t.cols - t.Bp);
                     q.N = g.hpad; q.hp = g.hpad; q.hv = H;
-                    hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(g.nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
-                    TD_LAUNCH_CHECK();
+                    rc = td_dw_gemm(q, g.nu, stream);
+                    if (rc != TD_OK) return rc;
                 }
                 // biases
                 hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(H, 4)), dim3(256), 0, stream,
