@@ -14,7 +14,7 @@ extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
 
 // wide layers (rnn_wide.hip) keep the recurrent state of a step in a scratch region, one per direction
 static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
-    return g.nu % 4 == 0 ? (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.nu * 1024 * sizeof(float) : 0;
+    return g.nu >= 2 ? (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.nu * 1024 * sizeof(float) : 0;
 }
 
 // Which recurrent-layer kernel runs a layer.  rnn_layer.h (a wave = a batch block, all units) needs
@@ -27,10 +27,13 @@ static bool td_use_wide(const TdRnnGeom &g, int nbb) {
     // A/B switch for measurements: TIMEDIFF_LAYER_KERNEL=batch forces rnn_layer.h, =units forces rnn_wide.hip
     static const char *force = getenv("TIMEDIFF_LAYER_KERNEL");
     if (force && force[0] == 'b') return false;
-    if (force && force[0] == 'u') return g.nu % 4 == 0;
+    if (force && force[0] == 'u') return g.nu >= 2;
+    // widths of 2, 3 or 6 unit blocks (HiRID's 36, MIMIC-III's 92, ...): one block per wave, single-block workgroups
+    // only, so just for the small batches
+    if (g.nu % 4 != 0) return g.nu >= 2 && nbb * g.dirs <= 64;
     // measured at H = 256: the unit-split kernel wins while its workgroups (one or two batch
     // blocks each) fit the chip in one round, i.e. up to 8192 sequences bidirectional
-    return g.nu % 4 == 0 && td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs <= 128;
+    return td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs <= 128;
 }
 
 // workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]

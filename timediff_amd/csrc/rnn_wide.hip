@@ -41,7 +41,10 @@ __device__ __forceinline__ void tdw_static_for(F &&f) {
 template <int NUW, int NB, bool L0, bool GRU, bool SAVE, int WAVES = 4>
 __global__ __launch_bounds__(64 * WAVES, 1) void td_rnn_layer_wide_kernel(TdLayerParams p, int kx0) {
     constexpr int NG = GRU ? 3 : 4, NU = WAVES * NUW, KH = 2 * NU;
-    constexpr int KC = WAVES == 8 ? 2 : 4, CH = KC * NG;   // k-steps / weight fragments per pipeline chunk (256 registers per wave with eight waves)
+    // k-steps / weight fragments per pipeline chunk: 4 k-steps where a wave has 512 registers and KH allows an even
+    // number of chunks, fewer for the 6- and 8-wave variants (256 registers per wave) and the narrow widths
+    constexpr int KC = (WAVES >= 6) ? 2 : (KH % 8 == 0 ? 4 : (KH % 4 == 0 ? 2 : 1)), CH = KC * NG;
+    static_assert((KH / KC) % 2 == 0, "the two-chunk pipeline needs an even number of chunks per part");
     // h_{t-1} as B fragments, [NB][KH] KiB.  Double buffered when two copies fit (one barrier per step, h_t written
     // straight into the other buffer); otherwise single buffered: h_t goes to the layer output first and is copied
     // back into LDS between two barriers.
@@ -310,7 +313,7 @@ static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, 
     return tdw_dispatch2<NUW, 1, 4>(gru, save, p, layer0, kx0, stream);
 }
 
-// nu: padded 32-unit blocks (4, 8, 12, 16, 24 or 32); kx0: layer-0 input k-steps
+// nu: padded 32-unit blocks (2, 3, 4, 6, 8, 12, 16, 24 or 32); kx0: layer-0 input k-steps
 int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
     if (!p.state) {
         td_set_error("wide recurrent layer: no state scratch");
@@ -321,7 +324,11 @@ int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool
         return TD_ERR_INVALID;
     }
     switch (nu) {
-        case 4: return tdw_dispatch<1>(gru, save, p, layer0, kx0, stream);   // small batches at H <= 256: td_use_wide()
+        // small batches at H <= 256 (td_use_wide): one unit block per wave, as many waves as blocks
+        case 2: return tdw_dispatch2<1, 1, 2>(gru, save, p, layer0, kx0, stream);
+        case 3: return tdw_dispatch2<1, 1, 3>(gru, save, p, layer0, kx0, stream);
+        case 6: return tdw_dispatch2<1, 1, 6>(gru, save, p, layer0, kx0, stream);
+        case 4: return tdw_dispatch<1>(gru, save, p, layer0, kx0, stream);
         case 8: return tdw_dispatch<2>(gru, save, p, layer0, kx0, stream);
         case 12: return tdw_dispatch<3>(gru, save, p, layer0, kx0, stream);
         case 16: return tdw_dispatch<4>(gru, save, p, layer0, kx0, stream);
