@@ -1,5 +1,5 @@
 // The unit-split recurrent layer: wide hidden sizes (256 < H <= 1024: BASELINE.json configs[3], [4]) and small
-// batches at any width that is a multiple of 128 (rnn.hip: td_use_wide), plus the head for wide layers.
+// batches at any width of two or more 32-unit blocks (rnn.hip: td_use_wide), plus the head for wide layers.
 //
 // Above H = 256 the state of 32 sequences (cell state fp32 + h as B fragments) no longer fits one wave's
 // registers, so the decomposition of rnn_layer.h turns by 90 degrees: a workgroup owns NB batch blocks of 32
@@ -8,6 +8,7 @@
 //   NB = 2, WAVES = 4   the batch fills the chip with two blocks per workgroup (more than 256 single-block workgroups)
 //   NB = 1, WAVES = 4   fewer workgroups than CUs: one block each
 //   NB = 1, WAVES = 8   at most 32 workgroups (the reference's batch sizes): a second wave per SIMD hides L2 latency
+//   NB = 1, WAVES = 2, 3, 6 (one block per wave)   widths of 2, 3 or 6 unit blocks (HiRID's 36, MIMIC-III's 92) at small batches
 // The fp32 recurrent state of a block lives in L2/HBM between steps (read under the block's last MFMAs, 8 H bytes
 // per sequence and step: nothing next to the weight stream), which leaves the registers to the accumulators and
 // the operand pipeline.  h_{t-1} of all units is the B operand of every wave's recurrent k-steps and lives in LDS
