@@ -804,17 +804,20 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
             TD_REQUIRE(gw[0] && gw[1] && gw[2] && gw[3], "NULL gradient pointer for layer %d dir %d", l, d);
             const __bf16 *dapl = (const __bf16 *)(ws + t.dapl[l][d]);
             const int In = l == 0 ? cfg->c_in : DH;
-            for (int gate = 0; gate < G; ++gate) {
+            // LSTM with an unpadded width: the four gates' slabs of d a and their rows of d W are contiguous, so all
+            // gates go in one GEMM / one bias reduction per tensor (GM = 4 gates per call)
+            const int GM = (!cfg->gru && g.hpad == H) ? G : 1;
+            for (int gate = 0; gate < G; gate += GM) {
                 const int slab_x = gate, slab_h = (cfg->gru && gate == 2) ? 3 : gate;
                 TdDwParams q;
                 q.kchunk = 2048;
                 // W_ih
                 q.A = dapl + (size_t)slab_x * t.dapl_slab_elems; q.lda = t.cols;
                 q.B = (const __bf16 *)(ws + t.plain[l]); q.ldb = t.cols;
-                q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = H; q.K = (int)t.cols;
+                q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = GM * H; q.K = (int)t.cols;
                 if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
                 else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
-                rc = td_dw_gemm(q, g.nu, stream);
+                rc = td_dw_gemm(q, GM * g.nu, stream);
                 if (rc != TD_OK) return rc;
                 // W_hh: h_{t-1} is this direction's own output one step earlier in its processing order
                 if (L > 1) {
@@ -824,12 +827,12 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                     q.B = d == 0 ? hpl : hpl + t.Bp;
                     q.C = gw[1] + (size_t)gate * H * H; q.ldc = H; q.K = (int)(t.cols - t.Bp);
                     q.N = g.hpad; q.hp = g.hpad; q.hv = H;
-                    rc = td_dw_gemm(q, g.nu, stream);
+                    rc = td_dw_gemm(q, GM * g.nu, stream);
                     if (rc != TD_OK) return rc;
                 }
                 // biases
-                hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(H, 4)), dim3(256), 0, stream,
-                                   dapl + (size_t)slab_x * t.dapl_slab_elems, t.cols, H, t.cols, gw[2] + gate * H,
+                hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(GM * H, 4)), dim3(256), 0, stream,
+                                   dapl + (size_t)slab_x * t.dapl_slab_elems, t.cols, GM * H, t.cols, gw[2] + gate * H,
                                    slab_h == slab_x ? gw[3] + gate * H : (float *)nullptr);
                 TD_LAUNCH_CHECK();
                 if (slab_h != slab_x) {
