@@ -8,8 +8,13 @@ chain (prior draw -> T x (denoiser + reverse update) -> decode) for `--batch` se
 as a captured hipGraph.  Patients are sharded across ranks (disjoint Philox patient ids), no data-path
 collective: weak scaling.
 
-    python bench.py --gpus 1 --steps 1 --warmup 0
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A chain of 16 384 sequences takes ~30 s, so `--steps` / `--warmup` are CAPS under a wall budget (`--budget-s`, default
+240 s for warm-up + timed chains together): warm-up is a short-T pass through every kernel plus at most one full
+chain, and timed chains stop when the next one would not fit.  The JSON line reports the `steps` and `warmup`
+actually executed (and the requested caps beside them); every rank runs the same number of chains.
 """
 import argparse
 import ctypes as C
@@ -131,8 +136,9 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3, help="cap on timed full chains (see --budget-s)")
+    ap.add_argument("--warmup", type=int, default=1, help="cap on untimed full chains (at most one is run)")
+    ap.add_argument("--budget-s", type=float, default=240.0, help="wall budget for warm-up + timed chains")
     ap.add_argument("--batch", type=int, default=16384, help="sequences per GPU per chain")
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--hidden", type=int, default=256)
@@ -141,7 +147,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
     ap.add_argument("--train-batch", type=int, default=32, help="training probe: batch per micro-batch (reference default 32)")
-    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-oracle baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,24 +185,45 @@ def main():
         # every chain draws fresh patients: ids are disjoint across ranks and chains
         return sampler.sample(B, seed=2023, patient0=(i * world + rank) * B)
 
+    def agree_max(x):
+        """The same number on every rank (max over ranks): all ranks take the same stop decision."""
+        if world == 1:
+            return x
+        tt = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     # untimed: one short pass through every kernel so allocations and code objects are in place
     pre = SamplerKernels(den, DiffusionKernels(cols["num"], cols["cat"], cols["K"], L, 4, make_tables(4, "cosine"),
                                                len(cols["num"]) + len(cols["cat"]), dev))
     pre.sample(B, seed=1)
-    for w in range(args.warmup):
-        chain(-1 - w)
+    barrier()
+    budget0 = time.time()
+    est = None                       # seconds per chain, agreed over ranks
+    warmup_done = 0
+    if args.warmup > 0:              # at most ONE full untimed chain, whatever the cap says
+        t0 = time.time()
+        chain(-1)
+        torch.cuda.synchronize()
+        est = agree_max(time.time() - t0)
+        warmup_done = 1
     barrier()
     t0 = time.time()
-    for i in range(args.steps):
-        out = chain(i)
+    steps_done = 0
+    while steps_done < args.steps:
+        used = agree_max(time.time() - budget0)
+        # the first timed chain always runs; later ones only if they fit the budget
+        if steps_done > 0 and used + est > args.budget_s:
+            break
+        c0 = time.time()
+        out = chain(steps_done)
+        torch.cuda.synchronize()     # a chain is ~30 s: the sync between chains is noise, and it bounds the run
+        est = agree_max(time.time() - c0)
+        steps_done += 1
     barrier()
-    elapsed = time.time() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = agree_max(time.time() - t0)
     assert torch.isfinite(out).all()
-    value = world * B * args.steps / elapsed
+    value = world * B * steps_done / elapsed
 
     result = None
     if rank == 0:
@@ -231,7 +259,7 @@ def main():
                         avg_launch_ms=avg_s * 1e3, flops_per_launch=flops_launch)
         base = None
         if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only: the other ranks would wait on it
-            base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()})
+            base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()}, args.cpu_seconds)
         train = None
         if world == 1 and not args.no_train_probe:
             del out, z, idx, mo
@@ -241,8 +269,9 @@ def main():
         fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
         result = {
             "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,
-            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "unit": "sequences/s", "n_gpus": world, "steps": steps_done, "warmup": warmup_done,
+            "steps_requested": args.steps, "warmup_requested": args.warmup, "budget_s": args.budget_s,
+            "ms_per_step": elapsed / steps_done * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "ETDiff eICU-shaped sampler: C_io=14 (4 continuous + 5 binary), L=272, "
                                    f"3-layer bidirectional LSTM H={H}, T={T}, random-init weights, Philox noise",
