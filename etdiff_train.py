@@ -21,7 +21,7 @@ from models.ETDiff.gaussian_diffusion import GaussianDiffusion
 from models.ETDiff.mixed_diffusion import MixedDiffusion
 from models.ETDiff.utils import TimeSeriesDataset
 from timediff_amd.data import TensorSeriesDataset
-from timediff_amd.parallel import gather_samples, patient_shard
+from timediff_amd.parallel import patient_shard
 
 # numerical / missingness-indicator channel maps per dataset (reference etdiff_train.py:24-29)
 COLUMNS_DICT = {
@@ -105,20 +105,64 @@ def collect_samples(model, num_samples, batch_size=20, min=None, max=None, posit
     return samples
 
 
-def collect_samples_sharded(model, num_samples, batch_size, min, max, rank, world):
-    """Patient-sharded collection: every rank draws its slice of the patient range, rank 0 assembles."""
-    start, stop = patient_shard((num_samples // batch_size) * batch_size, rank, world)
-    local = []
+def _sample_dims(model):
+    """(channels, seq_len) of what model.sample returns: create_samples (mixed_diffusion.py:173-179) sizes the
+    result `channels - n_cat`; the Gaussian process returns all its channels."""
+    n_cat = len(getattr(model, "categorical_features_indices", []))
+    return model.channels - n_cat, model.seq_length
+
+
+@torch.no_grad()
+def collect_samples_to_file(model, num_samples, batch_size, min, max, path, rank=0, world=1, seed=None):
+    """collect_samples + reverse_normalize + np.save (reference etdiff_train.py:150-166, :190-193, :286) as one
+    streaming, patient-sharded pass: rank r draws the patients [start, stop) of the global range in GPU-filling
+    chunks (Philox streams keyed by the global patient id, so the file does not depend on the number of ranks or
+    on the chunking) and writes its rows of the `.npy` itself (timediff_amd.parallel.SampleWriter): no gather, no
+    host concatenation.  The D2H copy and the write of chunk i run while chunk i + 1's chain is on the GPU.
+    `seed`: the Philox seed every rank must share (drawn from torch's generator when None: seed_everything makes
+    that equal on all ranks)."""
+    from timediff_amd.parallel import SampleWriter
+    model.eval()
+    total = (num_samples // batch_size) * batch_size
+    channels, seq_len = _sample_dims(model)
+    writer = SampleWriter(path, total, channels, seq_len, min, max, rank, world)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if world > 1 and torch.distributed.is_initialized():     # rank 0's draw, whatever the others consumed
+            dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+            box = torch.tensor([seed], dtype=torch.int64, device=dev)
+            torch.distributed.broadcast(box, src=0)
+            seed = int(box.item())
+    import inspect
+    keep_on_device = "to_cpu" in inspect.signature(model.sample).parameters   # MixedDiffusion.sample moves to the CPU
+    chunk = int(os.environ.get("TIMEDIFF_SAMPLE_CHUNK", "16384"))
+    start, stop = patient_shard(total, rank, world)
+    pending = None            # (first row, pinned host tensor, copy-done event) of the previous chunk
     pos = start
-    while pos < stop:
-        n = builtins_min(batch_size, stop - pos)
-        local.append(model.sample(batch_size=n, patient0=pos))
-        pos += n
-    local = torch.cat(local, dim=0).cpu() if local else torch.empty(0)
-    full = gather_samples(local, (num_samples // batch_size) * batch_size)
-    if full is None:
-        return None
-    return reverse_normalize(full.squeeze().numpy(), min, max)
+    while pos < stop or pending is not None:
+        nxt = None
+        if pos < stop:
+            n = builtins_min(chunk, stop - pos)
+            kw = dict(batch_size=n, seed=seed, patient0=pos)
+            if keep_on_device:
+                kw["to_cpu"] = False
+            dev_out = model.sample(**kw)                    # enqueued; the GPU is busy for the whole chain
+            if dev_out.is_cuda:
+                host = torch.empty(dev_out.shape, dtype=dev_out.dtype, pin_memory=True)
+                host.copy_(dev_out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            else:
+                host, ev = dev_out, None
+            nxt = (pos, host, ev)
+            pos += n
+        if pending is not None:                             # write the previous chunk under this chunk's chain
+            p0, host, ev = pending
+            if ev is not None:
+                ev.synchronize()
+            writer.put(p0, host)
+        pending = nxt
+    return writer.close()
 
 
 builtins_min = min
@@ -143,12 +187,11 @@ def synthetic_dataset(data_name, n, cut_length, seed):
 
 
 def main(argv=None):
-    import os
     args = parse_arguments(argv)
     seed_everything(args.seed)
     run_id = create_id()
     wandb = None
-    if args.wandb:
+    if args.wandb and int(os.environ.get("RANK", "0")) == 0:
         import wandb as _wandb
         wandb = _wandb
         wandb.init(project=args.project_name, entity=args.entity, name=f"ETDiff_{run_id}", config=args)
@@ -184,7 +227,7 @@ def main(argv=None):
                     wandb=wandb, check_point_path=args.check_point_path, run_id=run_id)
     params = count_params(model)
     print(f"Number of parameters: {params}")
-    if args.wandb:
+    if wandb is not None:
         wandb.log({"total_params": params})
 
     if not args.eval:
@@ -197,17 +240,12 @@ def main(argv=None):
         sample_path = model_path_to_sample_path(args.eval_path)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     ema_model = etdiff.ema.ema_model
-    if world > 1 and args.diff_type == "mixed":
-        samples = collect_samples_sharded(ema_model.eval(), args.num_samples, args.sample_batch_size, etdiff.sample_min,
-                                          etdiff.sample_max, etdiff.rank, world)
-    else:
-        samples = collect_samples(model=ema_model, num_samples=args.num_samples, batch_size=args.sample_batch_size,
-                                  min=etdiff.sample_min, max=etdiff.sample_max, positive_only=False) if etdiff.rank == 0 else None
-    if samples is not None:
-        os.makedirs(os.path.dirname(sample_path) or ".", exist_ok=True)
-        np.save(sample_path, samples)
+    # every rank holds the same EMA weights after training (rank 0's after --eval loads on every rank) and the same
+    # torch seed, so the shared Philox seed needs no exchange
+    collect_samples_to_file(ema_model, args.num_samples, args.sample_batch_size, etdiff.sample_min, etdiff.sample_max,
+                            sample_path, etdiff.rank, world)
+    if etdiff.rank == 0:
         print(f"Saved synthetic samples to {sample_path}")
-
 
 if __name__ == "__main__":
     main()

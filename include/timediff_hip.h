@@ -13,8 +13,12 @@
  *   - tensors are dense row-major in the reference's (torch) layouts; weights are read in torch's
  *     native layout (LSTM gate rows i,f,g,o; GRU gate rows r,z,n);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
- *     enqueues work, none synchronises, allocates or frees device memory: scratch comes in through
- *     the `workspace` arguments sized by the matching *_bytes() query;
+ *     enqueues work and takes its scratch through the `workspace` arguments sized by the matching
+ *     *_bytes() query.  Exceptions, each once per process: td_rnn_backward[_cb] creates a rocBLAS handle
+ *     (which owns a device workspace) on its first call; td_sample_chain instantiates and caches a
+ *     hipGraph (released by td_sample_chain_release); td_profile_enable creates HIP events;
+ *   - limits of this build: hidden <= 1024, c_in <= 32, c_out <= 32, at most TD_MAX_CAT discrete variables
+ *     of at most TD_MAX_CLASSES classes each (the reference accepts any K_i, mixed_diffusion.py:44-51);
  *   - return value: TD_OK or an error code; td_last_error() returns the message (thread-local).
  */
 #ifndef TIMEDIFF_HIP_H
@@ -145,7 +149,8 @@ enum { /* rows of the (TD_TAB_COUNT, T) fp32 `tables` array = buffers registered
     TD_TAB_COUNT
 };
 
-#define TD_MAX_CAT 32 /* discrete variables per model */
+#define TD_MAX_CAT 32    /* discrete variables per model */
+#define TD_MAX_CLASSES 8 /* classes per discrete variable (per-thread register arrays in the fused kernels) */
 
 typedef struct td_diffusion_config {
     int32_t n_num;               /* continuous channels                                   */
@@ -236,6 +241,20 @@ TD_API int td_grad_norm(const float *grad, size_t n, float *norm, void *workspac
 TD_API int td_clip_adam_ema(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, size_t n,
                      const float *norm, float max_norm, float lr, float beta1, float beta2, float eps, int32_t step,
                      int32_t ema_mode, float ema_decay, void *stream);
+
+/* Kernel-selection knobs for tests and measurements, no counterpart in the reference (process-wide, not
+ * thread-safe against concurrent launches).
+ *   td_set_layer_kernel: which recurrent-layer kernel family runs hidden sizes <= 256.  AUTO picks by batch
+ *     (csrc/rnn.hip td_use_wide: the unit-split kernel of rnn_wide.hip below ~8192 sequences, the
+ *     batch-block kernel of rnn_layer.h above); BATCH / UNITS force one family (UNITS needs hidden > 32).
+ *   td_set_dw_gemm: weight-gradient GEMMs.  AUTO = rocBLAS where the shape has no column remap, the in-tree
+ *     split-K MFMA kernel otherwise; KERNEL = the in-tree kernel for every shape. */
+enum { TD_LAYER_KERNEL_AUTO = 0, TD_LAYER_KERNEL_BATCH = 1, TD_LAYER_KERNEL_UNITS = 2 };
+enum { TD_DW_GEMM_AUTO = 0, TD_DW_GEMM_KERNEL = 1 };
+TD_API int td_set_layer_kernel(int32_t mode);
+/* Which family a (cfg, batch) launch takes under the current mode: TD_LAYER_KERNEL_BATCH or _UNITS (-1: bad cfg). */
+TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch);
+TD_API int td_set_dw_gemm(int32_t mode);
 
 /* Measurement aid, no counterpart in the reference: while enabled, every recurrent-layer kernel of the
  * widest kind (layers above the first) launched outside graph capture is bracketed by HIP events on

@@ -1,0 +1,181 @@
+"""GPU parity of BOTH recurrent-layer kernel families at hidden sizes <= 256, each pinned explicitly.
+
+csrc/rnn.hip (td_use_wide) sends a launch either to the batch-block kernel of rnn_layer.h (a wave owns 32 sequences
+and all units: the kernel bench.py times, taken above ~8192 sequences) or to the unit-split kernel of rnn_wide.hip
+(small batches).  The golden-vector tests run at small batches, i.e. through the unit-split kernel wherever it
+exists, so this file
+  * forces the batch-block family with td_set_layer_kernel and walks EVERY instantiation rnn_launch.h lists
+    (hidden blocks 1, 2, 3, 4, 6, 8 x LSTM / GRU x inference / saving; layer-0 input k-steps 1 and 2; one and two
+    directions) against the oracle: forward (bf16-emulating oracle), saving forward == inference forward bit for bit,
+    parameter gradients (fp32 oracle);
+  * runs the AUTOMATIC dispatch just above each switch point (H = 256 / 128 above 8192 sequences, H = 192 / 92 / 40
+    above 1024) and asserts through td_rnn_layer_kernel_choice that the batch-block kernel ran: the configuration
+    bench.py measures (H = 256, 3 layers, bidirectional, B > 8192) is checked at full width with a short sequence.
+    Sequences are independent, so the oracle is evaluated on a subset of them (first tiles, strided middle, the
+    ragged tail); gradients are checked with grad_y non-zero on that subset only (every other sequence still
+    flows through every kernel and must contribute exactly nothing).
+Tolerances as in test_gpu_parity.py (reference semantics: blocks.py:282-297).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from test_gpu_parity import BF16_EMUL_ATOL, _rel, cu, den_kernels
+from test_gpu_wide import _inputs, random_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def knob():
+    """td_set_layer_kernel, restored to AUTO afterwards."""
+    from timediff_amd import _lib
+    L = _lib.lib()
+
+    def set_mode(mode):
+        _lib.check(L.td_set_layer_kernel(mode))
+    yield set_mode
+    L.td_set_layer_kernel(_lib.LAYER_KERNEL_AUTO)
+
+
+def _choice(den, B):
+    from timediff_amd import _lib
+    return _lib.lib().td_rnn_layer_kernel_choice(C.byref(den.cfg), B)
+
+
+def _check_forward_and_grads(den, sd, x, t, gy, rows, dev, tol_y=BF16_EMUL_ATOL):
+    """forward vs the bf16-emulating oracle on `rows`, saving forward == inference forward on ALL rows,
+    parameter gradients vs the fp32 oracle (grad_y is zero outside `rows`)."""
+    film = den.time_film(cu(t, dev))
+    y, hidden = den.forward(cu(x, dev), film=film, want_hidden=True)
+    y, hidden = y.cpu().numpy(), hidden.cpu().numpy()
+    assert np.isfinite(y).all()
+    y16, h16 = orc.Denoiser(sd, bf16=True).forward(x[rows], t[rows], want_hidden=True)
+    assert np.abs(hidden[rows] - h16).max() < BF16_EMUL_ATOL, np.abs(hidden[rows] - h16).max()
+    assert np.abs(y[rows] - y16).max() < tol_y, np.abs(y[rows] - y16).max()
+    y_tr = den.forward_train(cu(x, dev), film).cpu().numpy()
+    np.testing.assert_array_equal(y_tr, y)
+    g_layer, g_misc, g_film = den.backward(cu(gy, dev), film)
+    _, _, ref = orc.Denoiser(sd).backward(x[rows], t[rows], gy[rows])
+    for key, got in list(zip(den._lkeys, g_layer)) + list(g_misc.items()):
+        got = got.cpu().numpy()
+        assert np.isfinite(got).all(), key
+        assert _rel(got, ref[key]) < 3e-2, (key, _rel(got, ref[key]))
+    g_film = g_film.cpu().numpy()
+    off = np.ones(len(x), bool)
+    off[rows] = False
+    assert not g_film[off].any(), "a sequence with zero grad_y produced a FiLM gradient"
+    np.testing.assert_allclose(g_film.sum(0), ref["rnn.time_mlp.1.bias"], rtol=3e-2,
+                               atol=3e-2 * np.abs(ref["rnn.time_mlp.1.bias"]).max())
+
+
+# hidden sizes per unit-block count: one exact multiple of 32 and one padded width each
+NU_WIDTHS = {1: (32, 20), 2: (64, 40), 3: (96, 92), 4: (128, 100), 6: (192, 170), 8: (256, 250)}
+
+
+@pytest.mark.parametrize("gru", [0, 1])
+@pytest.mark.parametrize("nu", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("shape", ["bi_c14", "uni_c23"])
+def test_batch_block_family_forced(nu, gru, shape, dev, knob):
+    """Every template instantiation of td_rnn_layer_kernel: <NU, 1|2, L0>, <NU, 2NU|4NU, upper> x GRU x SAVE."""
+    from timediff_amd import _lib
+    knob(_lib.LAYER_KERNEL_BATCH)
+    dirs, Cc, n_num = (2, 14, 4) if shape == "bi_c14" else (1, 23, 7)
+    H = NU_WIDTHS[nu][0 if shape == "bi_c14" else 1]
+    B, L, layers = 150, 5, 3        # 5 batch blocks: the second workgroup has one live wave and three clamped ones
+    sd = random_state(H, Cc, layers, dirs, gru, seed=100 * nu + 10 * gru + dirs)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B) == _lib.LAYER_KERNEL_BATCH
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=nu)
+    gy = (rng.standard_normal((B, Cc, L)) / (B * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
+
+
+# (H, gru, dirs, B): just above the automatic switch to the batch-block kernel
+AUTO_CASES = [
+    (256, 0, 2, 8192 + 40),     # bench.py's configuration (BASELINE.json configs[1]/[2]): <8, 1, L0> and <8, 32, upper>
+    (256, 1, 2, 8192 + 40),
+    (128, 0, 2, 8192 + 40),
+    (256, 0, 1, 16384 + 40),
+    (192, 0, 2, 1024 + 40),
+    (92, 0, 2, 1024 + 40),      # MIMIC-III width (configs[0]) at the large-batch sampler's side of the switch
+    (40, 1, 2, 1024 + 40),      # HiRID-like width
+]
+
+
+@pytest.mark.parametrize("H,gru,dirs,B", AUTO_CASES)
+def test_auto_dispatch_above_switch(H, gru, dirs, B, dev):
+    from timediff_amd import _lib
+    L, layers, Cc, n_num = 6, 3, 14, 4
+    sd = random_state(H, Cc, layers, dirs, gru, seed=H + gru)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B) == _lib.LAYER_KERNEL_BATCH, "this batch should run the batch-block kernel"
+    assert _choice(den, 64) == (_lib.LAYER_KERNEL_UNITS if H > 32 else _lib.LAYER_KERNEL_BATCH)
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=H)
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(0, B, 97), np.arange(B - 48, B)]))
+    gy = np.zeros((B, Cc, L), np.float32)
+    gy[rows] = (rng.standard_normal((len(rows), Cc, L)) / (len(rows) * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, rows, dev, tol_y=2e-2)
+
+
+def test_families_agree_on_the_same_batch(dev, knob):
+    """The two families differ in summation order only: same inputs, outputs within the bf16 bound of each other,
+    and each one is deterministic run to run."""
+    from timediff_amd import _lib
+    H, Cc, B, L = 256, 14, 300, 7
+    sd = random_state(H, Cc, 3, 2, 0, seed=3)
+    den = den_kernels(sd, dev)
+    x, t, _ = _inputs(B, Cc, L, 4, seed=9)
+    out = {}
+    for mode in (_lib.LAYER_KERNEL_BATCH, _lib.LAYER_KERNEL_UNITS):
+        knob(mode)
+        assert _choice(den, B) == mode
+        a = den.forward(cu(x, dev), cu(t, dev)).cpu().numpy()
+        b = den.forward(cu(x, dev), cu(t, dev)).cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+        out[mode] = a
+    assert np.abs(out[_lib.LAYER_KERNEL_BATCH] - out[_lib.LAYER_KERNEL_UNITS]).max() < BF16_EMUL_ATOL
+
+
+def test_large_batch_chain_graph_equals_stepwise(dev):
+    """The sampler path bench.py runs (diffusion state -> layer-0 fragments -> batch-block layers -> head -> reverse
+    update, replayed as a hipGraph) above the switch: the graph chain equals the eager chain bit for bit, and the
+    first reverse step equals the tensor-level composition (build_input -> forward -> reverse_step_) whose pieces
+    the other tests pin to the oracle."""
+    from timediff_amd import _lib
+    from timediff_amd.ops import DiffusionKernels, SamplerKernels
+    H, L, T, B = 256, 6, 3, 8192 + 40
+    num, cat, K = [0, 2, 4, 6], [1, 3, 5, 7, 8], [2] * 5
+    sd = random_state(H, 14, 3, 2, 0, seed=21)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B) == _lib.LAYER_KERNEL_BATCH
+    tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
+    diff = DiffusionKernels(num, cat, K, L, T, tables, 9, dev)
+    sampler = SamplerKernels(den, diff)
+    a = sampler.sample(B, seed=5, patient0=1000)
+    b = sampler.sample(B, seed=5, patient0=1000, use_graph=False)
+    assert torch.equal(a, b)
+    # the same chain composed from the tensor-level entry points
+    z, idx = diff.prior(B, seed=5, patient0=1000)
+    film = den.time_film(torch.arange(T, device=dev))
+    for t in reversed(range(T)):
+        mo = den.forward(diff.build_input(z, idx), film=film[t:t + 1])
+        diff.reverse_step_(mo, z, idx, t, seed=5, patient0=1000)
+    want = diff.decode(z, idx)
+    assert torch.equal(a, want)
+    # and the denoiser output of the first step against the oracle on a subset of sequences
+    z, idx = diff.prior(B, seed=5, patient0=1000)
+    x_in = diff.build_input(z, idx)
+    mo = den.forward(x_in, film=film[T - 1:T]).cpu().numpy()
+    rows = np.unique(np.concatenate([np.arange(0, 33), np.arange(0, B, 211), np.arange(B - 40, B)]))
+    y16 = orc.Denoiser(sd, bf16=True).forward(x_in.cpu().numpy()[rows], np.full(len(rows), T - 1))
+    assert np.abs(mo[rows] - y16).max() < 2e-2

@@ -309,3 +309,71 @@ def test_eicu_width_training_path(dev):
     _, _, ref = o32.backward(x, t, gy)
     for key, got in list(zip(den._lkeys, g_layer)) + list(g_misc.items()):
         assert _rel(got.cpu().numpy(), ref[key]) < 3e-2, (key, _rel(got.cpu().numpy(), ref[key]))
+
+
+# ---------------------------------------------------------------------------------------------
+# north_star's chain criterion, literally (mixed_diffusion.py:437-446): teacher-forced per step
+# ---------------------------------------------------------------------------------------------
+def _split_x_in(x_in, n_num, K):
+    """Denoiser input (B, n_num + sum K, L) -> (z, class ids): the log-one-hot block of a variable holds 0 at its class."""
+    z = np.ascontiguousarray(x_in[:, :n_num])
+    idx, off = [], n_num
+    for k in K:
+        idx.append(x_in[:, off:off + k].argmax(axis=1))
+        off += k
+    return z, np.stack(idx, axis=1).astype(np.uint8) if idx else np.zeros((x_in.shape[0], 0, x_in.shape[2]), np.uint8)
+
+
+@pytest.mark.parametrize("name", ["eicu_lstm_T8", "k3mix_gru_T6", "hirid_lstm_uni_T5"])
+def test_chain_teacher_forced_margin_gate(name, dev):
+    """For every step of the reference's recorded chains: feed the RECORDED x_in[s] to the HIP denoiser, require
+    model_out within the bf16 tolerance of the reference's fp32 output, run the fused reverse update on it with
+    the recorded draws, and require
+      * the continuous state within the bound the measured model_out error implies
+        (|d z| <= c1_t * sqrt(1/abar_t - 1) * |d eps|, mixed_diffusion.py:196-218), and
+      * the sampled class indices BIT-EXACT wherever the reference's Gumbel-perturbed top-2 margin exceeds the
+        tolerance that error implies (a logit error d moves differences of log theta by at most 2 d).
+    The fraction of positions under the margin is printed."""
+    g = load_golden("sample_chain_" + name)
+    L, H, N, T, bidir, gru = [int(v) for v in g["cfg"]]
+    tables = {k: g["sd." + k] for k in orc._TABLE_MAP.values()}
+    sd = sub(g, "sd.model.")
+    K = [int(k) for k in g["K"]]
+    n_num, n_cat = len(g["num_idx"]), len(K)
+    c_io = n_num + sum(K)
+    den = den_kernels(sd, dev)
+    dk = diff_kernels(g, L, T, dev, tables=tables, data_channels=c_io - n_cat)
+    od = orc.Diffusion(n_num, K, L, T, tables=tables)
+    B = g["z_T"].shape[0]
+    below, total, flips = 0, 0, 0
+    for s in range(T):
+        t = T - 1 - s
+        x_in = g["x_in"][s]
+        mo = den.forward(cu(x_in, dev), cu(np.full(B, t), dev))
+        err = np.abs(mo.cpu().numpy() - g["model_out"][s])
+        assert err.max() < BF16_REF_ATOL, (s, err.max())
+        z0, idx0 = _split_x_in(x_in, n_num, K)
+        z, idx = cu(z0, dev), cu(idx0, dev)
+        dk.reverse_step_(mo, z, idx, t, cu(g["noise"][s], dev), cu(g["uniforms"][s], dev))
+        # the reference's own next state: the next step's recorded input, or the decoded sample after the last step
+        if s + 1 < T:
+            z_ref, idx_ref = _split_x_in(g["x_in"][s + 1], n_num, K)
+        else:
+            z_ref = g["sample"][:, list(g["num_idx"])] * 2 - 1
+            idx_ref = g["sample"][:, list(g["cat_idx"])].astype(np.uint8)
+        amp = float(tables["posterior_mean_coef1"][t] * tables["sqrt_recipm1_alphas_cumprod"][t])
+        bound = amp * float(err[:, :n_num].max()) + 2e-5
+        assert np.abs(z.cpu().numpy() - z_ref).max() <= bound, (s, np.abs(z.cpu().numpy() - z_ref).max(), bound)
+        if n_cat:
+            _, _, det = od.reverse_step(g["model_out"][s], z0, idx0, t, g["noise"][s], g["uniforms"][s], details=True)
+            margin = od.gumbel_margin(det["log_theta"], g["uniforms"][s])
+            tol = 2.0 * float(err[:, n_num:].max()) + (1e-3 if t <= 10 else 1e-5)
+            safe = margin > tol
+            got = idx.cpu().numpy()
+            assert np.array_equal(got[safe], idx_ref[safe]), (s, int((got[safe] != idx_ref[safe]).sum()))
+            below += int((~safe).sum())
+            total += safe.size
+            flips += int((got != idx_ref).sum())
+    if total:
+        print(f"\n[{name}] positions under the Gumbel margin: {below}/{total} = {below / total:.4f}; "
+              f"indices differing from the reference there: {flips}")

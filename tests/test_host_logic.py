@@ -85,43 +85,85 @@ def test_patient_shard_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, out):
+class _FakeSampler:
+    """Stands in for MixedDiffusion.sample: the value of a row depends on (seed, global patient id) only."""
+    channels, seq_length, categorical_features_indices = 3, 4, []
+
+    def __init__(self):
+        self.calls = []
+
+    def eval(self):
+        return self
+
+    @staticmethod
+    def expected(total, seed):
+        ids = np.arange(total, dtype=np.float32)[:, None, None]
+        return (ids * 0.25 + seed + np.arange(3, dtype=np.float32)[None, :, None] * 0.5 + np.zeros((1, 1, 4), np.float32))
+
+    def sample(self, batch_size, seed=None, patient0=0, to_cpu=True):
+        self.calls.append(batch_size)
+        return torch.from_numpy(self.expected(patient0 + batch_size, seed)[patient0:])
+
+
+def _worker(rank, world, port, out, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
-    from timediff_amd.parallel import all_reduce_mean_, gather_samples, patient_shard
+    import etdiff_train as cli
+    from timediff_amd.parallel import all_reduce_mean_, patient_shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # data-parallel gradient exchange: mean of the ranks' flat buffers
         flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
         all_reduce_mean_(flat)
         assert torch.allclose(flat, torch.arange(10, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
-        # patient-sharded sampling: rank-local slices keyed by GLOBAL patient id reassemble on rank 0
-        total = 11
-        a, b = patient_shard(total, rank, world)
-        local = torch.arange(a, b, dtype=torch.float32)[:, None, None].expand(-1, 3, 4).contiguous()
-        full = gather_samples(local, total)
-        if rank == 0:
-            assert full.shape == (total, 3, 4)
-            assert torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32))
-        else:
-            assert full is None
+        # patient-sharded sampling through the streaming writer: every rank draws its slice of the patient range
+        # (values keyed by the GLOBAL patient id, like the Philox streams) and writes its rows of the .npy itself
+        model = _FakeSampler()
+        mn, mx = np.zeros((1, 3, 1), np.float32), np.full((1, 3, 1), 2.0, np.float32)
+        os.environ["TIMEDIFF_SAMPLE_CHUNK"] = "4"
+        path = cli.collect_samples_to_file(model, 23, 2, mn, mx, out_path, rank, world, seed=5)
+        a, b = patient_shard(22, rank, world)
+        assert sum(model.calls) == b - a and max(model.calls) <= 4
+        got = np.load(path)
+        assert got.shape == (22, 3, 4) and got.dtype == np.float32
+        np.testing.assert_array_equal(got, _FakeSampler.expected(22, 5) * 2.0)
         dist.barrier()
         out.put((rank, "ok"))
     finally:
         dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
+def test_world_size_2_gloo(tmp_path):
+    """Two gloo ranks: the gradient mean, and the sharded sample file equals the single-rank file for the same
+    (seed, patient ids)."""
+    import etdiff_train as cli
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    out_path = str(tmp_path / "two" / "samples.npy")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, out_path)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+    single = cli.collect_samples_to_file(_FakeSampler(), 23, 2, np.zeros((1, 3, 1), np.float32), np.full((1, 3, 1), 2.0, np.float32),
+                                         str(tmp_path / "one" / "samples.npy"), 0, 1, seed=5)
+    np.testing.assert_array_equal(np.load(single), np.load(out_path))
+
+
+def test_sample_writer_squeezes_like_the_reference(tmp_path):
+    """torch.cat(samples).squeeze() (etdiff_train.py:163): size-1 axes are dropped from the saved array."""
+    from timediff_amd.parallel import SampleWriter
+    w = SampleWriter(str(tmp_path / "s.npy"), 6, 1, 5)
+    w.put(0, np.arange(30, dtype=np.float32).reshape(6, 1, 5))
+    w.close()
+    got = np.load(tmp_path / "s.npy")
+    assert got.shape == (6, 5)
+    np.testing.assert_array_equal(got, np.arange(30, dtype=np.float32).reshape(6, 5))
+    with pytest.raises(AssertionError):
+        SampleWriter(str(tmp_path / "t.npy"), 4, 2, 3).put(3, np.zeros((2, 2, 3), np.float32))
 
 
 def test_dataset_cache_roundtrip(tmp_path):

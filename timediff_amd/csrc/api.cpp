@@ -14,7 +14,32 @@ void td_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *td_last_error(void) { return g_err; }
-extern "C" int td_version(void) { return 100; }
+extern "C" int td_version(void) { return 200; }
+
+// ---------------------------------------------------------------------------------------------
+// Explicit kernel-selection knobs (tests and measurements flip them in-process).  No counterpart in the reference.
+// ---------------------------------------------------------------------------------------------
+static int g_layer_kernel = TD_LAYER_KERNEL_AUTO;
+static int g_dw_gemm = TD_DW_GEMM_AUTO;
+int td_layer_kernel_mode(void) { return g_layer_kernel; }
+int td_dw_gemm_mode(void) { return g_dw_gemm; }
+
+extern "C" int td_set_layer_kernel(int32_t mode) {
+    if (mode != TD_LAYER_KERNEL_AUTO && mode != TD_LAYER_KERNEL_BATCH && mode != TD_LAYER_KERNEL_UNITS) {
+        td_set_error("td_set_layer_kernel: unknown mode %d", mode);
+        return TD_ERR_INVALID;
+    }
+    g_layer_kernel = mode;
+    return TD_OK;
+}
+extern "C" int td_set_dw_gemm(int32_t mode) {
+    if (mode != TD_DW_GEMM_AUTO && mode != TD_DW_GEMM_KERNEL) {
+        td_set_error("td_set_dw_gemm: unknown mode %d", mode);
+        return TD_ERR_INVALID;
+    }
+    g_dw_gemm = mode;
+    return TD_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline probe).

@@ -3,26 +3,27 @@
 // is the right tool; td_dw_gemm_kernel (rnn_train.hip) stays for the shapes that need its column remap (hidden
 // sizes that are not a multiple of 32, the first layer's few input channels).
 #include <rocblas/rocblas.h>
-#include <stdlib.h>
 
 #include "common.h"
 
 static rocblas_handle g_blas = nullptr;
 
 // C[m][n] += sum_k A[m][k] B[n][k]; A, B row-major bf16 with k contiguous (lda, ldb), C row-major fp32 (ldc).
-// Returns TD_OK, or TD_ERR_UNSUPPORTED when the caller should fall back to its own kernel.
+// One path per shape: the caller (td_dw_gemm, rnn_train.hip) decides from the shape alone whether this runs; a failure
+// here is an error, never a silent switch to another kernel.
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
                    hipStream_t stream) {
-    static const char *force = getenv("TIMEDIFF_DW_GEMM");   // =kernel: never use the library (measurements)
-    if (force && force[0] == 'k') return TD_ERR_UNSUPPORTED;
-    if (lda > 0x7fffffff || ldb > 0x7fffffff) return TD_ERR_UNSUPPORTED;
     if (!g_blas) {
         if (rocblas_create_handle(&g_blas) != rocblas_status_success) {
             g_blas = nullptr;
-            return TD_ERR_UNSUPPORTED;
+            td_set_error("rocblas_create_handle failed");
+            return TD_ERR_HIP;
         }
     }
-    if (rocblas_set_stream(g_blas, stream) != rocblas_status_success) return TD_ERR_UNSUPPORTED;
+    if (rocblas_set_stream(g_blas, stream) != rocblas_status_success) {
+        td_set_error("rocblas_set_stream failed");
+        return TD_ERR_HIP;
+    }
     const float one = 1.0f;
     // column-major view: C' (N x M, ld ldc) = Bc^T (N x K) . Ac (K x M), Bc = B as (K x N, ld ldb), Ac = A as (K x M, ld lda)
     rocblas_status st = rocblas_gemm_ex(g_blas, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, B,

@@ -4,7 +4,8 @@
 #include "rnn_geom.h"
 
 #include <math.h>
-#include <stdlib.h>
+
+int td_layer_kernel_mode(void);   // api.cpp
 
 extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
     TdRnnGeom g;
@@ -24,16 +25,22 @@ static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
 // latency accordingly.  Always rnn_wide.hip above H = 256.
 static bool td_use_wide(const TdRnnGeom &g, int nbb) {
     if (g.nu > 8) return true;
-    // A/B switch for measurements: TIMEDIFF_LAYER_KERNEL=batch forces rnn_layer.h, =units forces rnn_wide.hip
-    static const char *force = getenv("TIMEDIFF_LAYER_KERNEL");
-    if (force && force[0] == 'b') return false;
-    if (force && force[0] == 'u') return g.nu >= 2;
+    // explicit A/B switch (td_set_layer_kernel): tests pin each kernel family, measurements compare them
+    const int force = td_layer_kernel_mode();
+    if (force == TD_LAYER_KERNEL_BATCH) return false;
+    if (force == TD_LAYER_KERNEL_UNITS) return g.nu >= 2;
     // widths of 2, 3 or 6 unit blocks (HiRID's 36, MIMIC-III's 92, ...): one block per wave, single-block workgroups
     // only, so just for the small batches
     if (g.nu % 4 != 0) return g.nu >= 2 && nbb * g.dirs <= 64;
     // measured at H = 256: the unit-split kernel wins while its workgroups (one or two batch
     // blocks each) fit the chip in one round, i.e. up to 8192 sequences bidirectional
     return td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs <= 128;
+}
+
+extern "C" int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch) {
+    TdRnnGeom g;
+    if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0) return -1;
+    return td_use_wide(g, td_cdiv(batch, TD_WAVE_BATCH)) ? TD_LAYER_KERNEL_UNITS : TD_LAYER_KERNEL_BATCH;
 }
 
 // workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]

@@ -18,7 +18,7 @@ int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, i
 
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
                          char *const *acts, float *const *saves, float *state, hipStream_t stream);
-// gemm_lib.cpp (rocBLAS); TD_ERR_UNSUPPORTED: use td_dw_gemm_kernel
+// gemm_lib.cpp (rocBLAS)
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
                    hipStream_t stream);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
@@ -682,12 +682,12 @@ __global__ __launch_bounds__(256) void td_dw_gemm_kernel(TdDwParams p) {
 }
 
 // The library GEMM where the shape allows (no column remap: hidden a multiple of 32, not the first layer's padded
-// channels), the kernel above otherwise.
+// channels; leading dimensions within rocBLAS's 32-bit range), the kernel above otherwise.  The choice depends on the
+// shape (and the explicit td_set_dw_gemm knob) only: a library failure is returned as an error.
+int td_dw_gemm_mode(void);   // api.cpp
 static int td_dw_gemm(const TdDwParams &q, int nu, hipStream_t stream) {
-    if (q.hp == q.hv) {
-        const int rc = td_dw_gemm_lib(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, stream);
-        if (rc != TD_ERR_UNSUPPORTED) return rc;
-    }
+    if (q.hp == q.hv && td_dw_gemm_mode() != TD_DW_GEMM_KERNEL && q.lda <= 0x7fffffff && q.ldb <= 0x7fffffff)
+        return td_dw_gemm_lib(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, stream);
     hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
     TD_LAUNCH_CHECK();
     return TD_OK;

@@ -28,7 +28,7 @@ from torch.utils.data import DataLoader
 
 from . import _lib
 from ._lib import check, lib, ptr
-from .data import cycle, exists
+from .data import exists
 from .parallel import layer_slices, uncovered_ranges
 
 logging.basicConfig(filename=None, format="[%(levelname)s:%(asctime)s] %(message)s", level=logging.INFO)
@@ -54,6 +54,18 @@ def _flatten_params_(module):
         p.data = flat[off:off + n].view_as(p)
         off += n
     return flat, params
+
+
+def _cycle_epochs(dl, sampler):
+    """cycle() (utils.py:107-110) that also advances a DistributedSampler's epoch each time the loader wraps, so
+    every pass over the data uses a new permutation (the same one on all ranks)."""
+    epoch = 0
+    while True:
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        for data in dl:
+            yield data
+        epoch += 1
 
 
 class EMA(nn.Module):
@@ -103,10 +115,15 @@ class ETDiff(nn.Module):
             raise RuntimeError("ETDiff trains on the MI355X only (no CPU fallback)")
         torch.cuda.set_device(local_rank)
         self._device = torch.device("cuda", local_rank)
-        if self.world > 1 and not torch.distributed.is_initialized():
+        # TIMEDIFF_DP_FORCE=1 runs the data-parallel code path (process group, communication stream, per-layer
+        # all-reduce behind events) even with ONE rank: RCCL accepts a single-rank communicator, which lets a
+        # one-GPU box execute the production (nccl) branch (tests/test_zz_gpu_data_parallel.py)
+        self._dp = self.world > 1 or os.environ.get("TIMEDIFF_DP_FORCE", "0") == "1"
+        if self._dp and not torch.distributed.is_initialized():
             # "nccl" is RCCL on ROCm; TIMEDIFF_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
             backend = os.environ.get("TIMEDIFF_DIST_BACKEND", "nccl")
-            torch.distributed.init_process_group(backend, **({"device_id": self._device} if backend == "nccl" else {}))
+            torch.distributed.init_process_group(backend, rank=self.rank, world_size=self.world,
+                                                 **({"device_id": self._device} if backend == "nccl" else {}))
         print(f"*** Using device: {self._device} ***", file=sys.stderr)
 
         self.timer = timeit.default_timer
@@ -128,13 +145,16 @@ class ETDiff(nn.Module):
         self.local_batch = train_batch_size // self.world
         sampler = None
         if self.world > 1:
-            sampler = torch.utils.data.distributed.DistributedSampler(dataset, self.world, self.rank, shuffle=True, seed=run_id)
+            # every rank must permute with the SAME seed (else the shards overlap): run_id is int(time.time()) per
+            # process in the CLI, so rank 0's value is broadcast
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, self.world, self.rank, shuffle=True,
+                                                                      seed=self._shared_int(run_id))
         # no loader workers: the dataset is one in-memory tensor (a batch is one gather: TimeSeriesDataset.__getitems__), and a worker would be forked from a process that has
         # already initialised HIP (a forked child can inherit a runtime lock that is held and never released: a rare hang)
         dl = DataLoader(dataset, batch_size=self.local_batch, shuffle=sampler is None, sampler=sampler, pin_memory=True,
                         num_workers=0, drop_last=self.world > 1,
                         collate_fn=_batch_passthrough if hasattr(dataset, "__getitems__") else None)
-        self.dl = cycle(dl)
+        self.dl = _cycle_epochs(dl, sampler)
 
         # flat buffers: weights, gradients, Adam moments, EMA weights
         self.lr, self.betas, self.eps = diff_lr, adam_betas, 1e-8
@@ -151,7 +171,7 @@ class ETDiff(nn.Module):
         self.flat_ema, _ = _flatten_params_(self.ema.ema_model)
         self._norm = torch.zeros(1, dtype=torch.float32, device=self._device)
         self._norm_ws = torch.empty(lib().td_grad_norm_workspace_bytes(), dtype=torch.uint8, device=self._device)
-        self._comm_stream = torch.cuda.Stream(device=self._device) if self.world > 1 else None
+        self._comm_stream = torch.cuda.Stream(device=self._device) if self._dp else None
         # The denoiser's backward accumulates straight into the flat gradient buffer (no AccumulateGrad pass); with
         # several ranks each recurrent layer's slice is all-reduced as soon as its gradient kernels are enqueued,
         # behind an event, on the communication stream, while BPTT goes on in the layers below.
@@ -168,6 +188,15 @@ class ETDiff(nn.Module):
             self._layer_slices = layer_slices(names, [p.numel() for p in self.params], self._n_layers)
         self.opt_step = 0
         self.step = 0
+
+    def _shared_int(self, value):
+        """rank 0's `value` on every rank."""
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            return int(value)
+        box = torch.tensor([int(value)], dtype=torch.int64, device=self._device if dist.get_backend() == "nccl" else "cpu")
+        dist.broadcast(box, src=0)
+        return int(box.item())
 
     @property
     def device(self):
@@ -211,7 +240,9 @@ class ETDiff(nn.Module):
         torch.save(weights, self.check_point_path)
 
     def load(self, path):
-        data = torch.load(path, map_location=self.device, weights_only=False)
+        # the checkpoint dict holds tensors, dicts, lists, tuples, numbers and None only (et_diff.py:208-216): the
+        # restricted unpickler loads it, and nothing in a user-supplied --eval_path gets executed
+        data = torch.load(path, map_location=self.device, weights_only=True)
         self.model.load_state_dict(data["diff_model"])     # copies into the flat buffer in place
         self.step = data["diff_step"]
         self._load_opt_state_dict(data["opt"])
@@ -246,7 +277,7 @@ class ETDiff(nn.Module):
 
     def _all_reduce_grads(self):
         """Whatever the per-layer reductions have not covered (everything when overlap is off), then join."""
-        if self.world == 1:
+        if not self._dp:
             return
         self._comm_stream.wait_stream(torch.cuda.current_stream())
         for a, b in uncovered_ranges(self.flat_grad.numel(), self._reduced):
@@ -280,7 +311,7 @@ class ETDiff(nn.Module):
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         for i in range(ga):
             if self._sink is not None:
-                overlap = self.world > 1 and self._overlap and i == ga - 1
+                overlap = self._dp and self._overlap and i == ga - 1
                 self._sink["on_layer_done"] = self._layer_reduce if overlap else None
             data = next(self.dl).to(self.device, non_blocking=True)
             loss = self.model(data) / ga
