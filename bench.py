@@ -185,6 +185,11 @@ def main():
         # every chain draws fresh patients: ids are disjoint across ranks and chains
         return sampler.sample(B, seed=2023, patient0=(i * world + rank) * B)
 
+    def note(msg):
+        """Progress on stderr (a chain takes ~30 s; the JSON line is the only thing on stdout)."""
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     def agree_max(x):
         """The same number on every rank (max over ranks): all ranks take the same stop decision."""
         if world == 1:
@@ -207,6 +212,7 @@ def main():
         torch.cuda.synchronize()
         est = agree_max(time.time() - t0)
         warmup_done = 1
+        note(f"warm-up chain of {B} sequences: {est:.1f} s")
     barrier()
     t0 = time.time()
     steps_done = 0
@@ -220,6 +226,7 @@ def main():
         torch.cuda.synchronize()     # a chain is ~30 s: the sync between chains is noise, and it bounds the run
         est = agree_max(time.time() - c0)
         steps_done += 1
+        note(f"timed chain {steps_done}: {est:.1f} s")
     barrier()
     elapsed = agree_max(time.time() - t0)
     assert torch.isfinite(out).all()
@@ -257,9 +264,11 @@ def main():
                         peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK_TFLOPS,
                         traffic=traffic, traffic_unit="bytes per launch (PMC)", launches_timed=cnt.value,
                         avg_launch_ms=avg_s * 1e3, flops_per_launch=flops_launch)
+        note(f"roofline probe: {cnt.value} launches, {avg_s * 1e3:.2f} ms each")
         base = None
         if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only: the other ranks would wait on it
             base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()}, args.cpu_seconds)
+        note("cpu baseline done" if base else "cpu baseline skipped")
         train = None
         if world == 1 and not args.no_train_probe:
             del out, z, idx, mo

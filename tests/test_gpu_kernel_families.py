@@ -52,9 +52,10 @@ def _choice(den, B):
     return _lib.lib().td_rnn_layer_kernel_choice(C.byref(den.cfg), B)
 
 
-def _check_forward_and_grads(den, sd, x, t, gy, rows, dev, tol_y=BF16_EMUL_ATOL):
+def _check_forward_and_grads(den, sd, x, t, gy, rows, dev, tol_y=2e-2):
     """forward vs the bf16-emulating oracle on `rows`, saving forward == inference forward on ALL rows,
-    parameter gradients vs the fp32 oracle (grad_y is zero outside `rows`)."""
+    parameter gradients vs the fp32 oracle (grad_y is zero outside `rows`).  Hidden state: 1e-2 (one bf16 step of an
+    O(1) value); the projected output sums D*H of them: 2e-2, as in test_gpu_wide.py."""
     film = den.time_film(cu(t, dev))
     y, hidden = den.forward(cu(x, dev), film=film, want_hidden=True)
     y, hidden = y.cpu().numpy(), hidden.cpu().numpy()
@@ -124,7 +125,7 @@ def test_auto_dispatch_above_switch(H, gru, dirs, B, dev):
     rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(0, B, 97), np.arange(B - 48, B)]))
     gy = np.zeros((B, Cc, L), np.float32)
     gy[rows] = (rng.standard_normal((len(rows), Cc, L)) / (len(rows) * L)).astype(np.float32)
-    _check_forward_and_grads(den, sd, x, t, gy, rows, dev, tol_y=2e-2)
+    _check_forward_and_grads(den, sd, x, t, gy, rows, dev)
 
 
 def test_families_agree_on_the_same_batch(dev, knob):
