@@ -192,6 +192,17 @@ TD_API int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, const fl
                   const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t, float loss_lambda, float scale,
                   float *loss, float *grad, void *workspace, void *stream);
 
+/* td_mixed_loss without the workspace argument.  No counterpart in the reference: it is for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * The block partials live in an 8 KiB file-scope device array of the library (one copy per GPU, held until the
+ * process ends); the call allocates and frees nothing.  Limits: batch * seq_len <= TD_NOALLOC_MAX_POSITIONS
+ * (TD_ERR_UNSUPPORTED beyond); calls that overlap on one GPU share the array and race: keep them on one stream.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */
+#define TD_NOALLOC_MAX_POSITIONS (1 << 27)
+TD_API int td_mixed_loss_noalloc(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *noise,
+                          const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t, float loss_lambda, float scale,
+                          float *loss, float *grad, void *stream);
+
 /* mixed_diffusion.py:429-435: z_T ~ N(0, I) (B, n_num, L) and the uniform categorical prior as class ids. */
 TD_API int td_sample_prior(const td_diffusion_config *cfg, int32_t batch, const float *noise, const float *uniforms,
                     td_rng rng, float *z, uint8_t *idx, void *stream);

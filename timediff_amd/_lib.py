@@ -69,6 +69,7 @@ _SIGS = {
     "td_q_sample_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, Rng, _P, _P, _P, _P, _P]),
     "td_mixed_loss_workspace_bytes": (C.c_size_t, [C.POINTER(DiffusionConfig), _I]),
     "td_mixed_loss": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "td_mixed_loss_noalloc": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P]),
     "td_sample_prior": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, Rng, _P, _P, _P]),
     "td_build_denoiser_input": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P]),
     "td_reverse_step_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _I, _P, _P, _P, Rng, _P]),

@@ -392,6 +392,52 @@ extern "C" int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// td_mixed_loss for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): the block partials live in a file-scope device array instead of a caller workspace.  Each GPU the
+// library runs on holds its own copy of the array (8 KiB) until the process ends; its device address is looked up
+// once per device with that device current (the array's NAME is a host-side stand-in, never a kernel argument).
+// Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race.  Nothing in
+// it has to start at zero: each launch overwrites the `blocks` partials the finishing kernel then reads.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) double td_loss_scratch[TD_LOSS_BLOCKS];
+#define TD_NOALLOC_MAX_DEVICES 64
+static double *g_loss_scratch_ptr[TD_NOALLOC_MAX_DEVICES];   // per device: the address of ITS copy of td_loss_scratch
+
+extern "C" int td_mixed_loss_noalloc(const td_diffusion_config *cfg, int32_t batch, const float *model_out,
+                                     const float *noise, const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t,
+                                     float loss_lambda, float scale, float *loss, float *grad, void *stream) {
+    int rc = td_check_diff(cfg, batch);
+    if (rc != TD_OK) return rc;
+    TD_REQUIRE(model_out && t && loss, "NULL argument");
+    TD_REQUIRE(cfg->n_num == 0 || noise, "noise required when n_num > 0");
+    TD_REQUIRE(cfg->n_cat == 0 || (x0_idx && xt_idx), "x0_idx / xt_idx required when n_cat > 0");
+    const size_t positions = (size_t)batch * cfg->seq_len;
+    if (positions > (size_t)TD_NOALLOC_MAX_POSITIONS) {
+        td_set_error("td_mixed_loss_noalloc: batch * seq_len = %zu exceeds the maximum of %zu positions; use td_mixed_loss",
+                     positions, (size_t)TD_NOALLOC_MAX_POSITIONS);
+        return TD_ERR_UNSUPPORTED;
+    }
+    int dev = -1;
+    TD_HIP(hipGetDevice(&dev));
+    TD_REQUIRE(dev >= 0 && dev < TD_NOALLOC_MAX_DEVICES, "device ordinal %d out of range", dev);
+    if (!g_loss_scratch_ptr[dev]) {   // first call on this device (not under graph capture: call once beforehand)
+        double *ptr = nullptr;
+        TD_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(td_loss_scratch)));
+        TD_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned NULL for the loss scratch");
+        g_loss_scratch_ptr[dev] = ptr;
+    }
+    double *partial = g_loss_scratch_ptr[dev];
+    const int blocks = td_grid(positions, TD_LOSS_BLOCKS);
+    hipLaunchKernelGGL(td_mixed_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *cfg, batch, td_sum_k(cfg),
+                       model_out, noise, x0_idx, xt_idx, t, loss_lambda, scale, grad, partial);
+    TD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(td_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)partial, blocks,
+                       1.0f, loss);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // sampler pieces (mixed_diffusion.py:425-454)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void td_prior_kernel(td_diffusion_config c, int B, int sumk, const float *noise,
