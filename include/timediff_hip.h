@@ -150,7 +150,7 @@ enum { /* rows of the (TD_TAB_COUNT, T) fp32 `tables` array = buffers registered
 };
 
 #define TD_MAX_CAT 32    /* discrete variables per model */
-#define TD_MAX_CLASSES 8 /* classes per discrete variable (per-thread register arrays in the fused kernels) */
+#define TD_MAX_CLASSES 32 /* classes per discrete variable (more than 8: scalar kernels instead of 4 positions per thread) */
 
 typedef struct td_diffusion_config {
     int32_t n_num;               /* continuous channels                                   */
@@ -217,6 +217,13 @@ TD_API int td_build_denoiser_input(const td_diffusion_config *cfg, int32_t batch
 TD_API int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t batch, const float *model_out, float *z,
                           uint8_t *idx, int32_t t_host, const int32_t *t_dev, const float *noise,
                           const float *uniforms, td_rng rng, void *stream);
+
+/* Parity aid: the posterior terms of one reverse step as the fused kernel computes them, nothing sampled or
+ * updated: x0 = clamp(predict_start_from_noise) (mixed_diffusion.py:196-201, :234-235) and mean = posterior mean
+ * (:210-218), both (B, n_num, L); log_theta = cat_q_posterior's normalised log-probabilities (:283-295), (B, sum K, L).
+ * Same kernel as td_reverse_step_mixed with the sampling replaced by these stores. */
+TD_API int td_reverse_step_terms(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *z,
+                          const uint8_t *idx, int32_t t, float *x0, float *mean, float *log_theta, void *stream);
 
 /* mixed_diffusion.py:448-453 (+ :59-66, :173-179, utils.py:95-99): (z+1)/2 and class ids scattered to
  * dataset channel order, (B, data_channels, L) fp32. */

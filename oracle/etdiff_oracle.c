@@ -76,7 +76,7 @@ static inline float u32_to_unit_open(uint32_t x) { return ((float)(x >> 8) + 1.0
 
 /* Draw layout (identical in timediff_amd/csrc/rng.h): counter = (patient id, position l, tag, block).
  * Normal block j (c3 = j) yields channels 4j..4j+3 by two Box-Muller pairs; uniform block j
- * (c3 = 0x10000 + j) yields the flat class slots 4j..4j+3. */
+ * (c3 = 0x10000 + j) yields the flat class slots 5j..5j+4 (five 24-bit fields of the 128 output bits). */
 EXPORT void or_philox_normals(uint64_t seed, uint32_t patient, uint32_t l, uint32_t tag, int n, float *out) {
     for (int j = 0; j * 4 < n; ++j) {
         uint32_t r[4];
@@ -85,18 +85,24 @@ EXPORT void or_philox_normals(uint64_t seed, uint32_t patient, uint32_t l, uint3
         for (int p = 0; p < 2; ++p) {
             float u1 = u32_to_unit_open(r[2 * p]), u2 = u32_to_unit(r[2 * p + 1]);
             float rad = sqrtf(-2.0f * logf(u1));
-            float ang = 6.283185307179586f * u2;
-            z[2 * p] = rad * cosf(ang);
-            z[2 * p + 1] = rad * sinf(ang);
+            double ang = 6.283185307179586476925 * (double)u2;   /* exact angle: the kernels use sincospi(2 u2) */
+            z[2 * p] = rad * (float)cos(ang);
+            z[2 * p + 1] = rad * (float)sin(ang);
         }
         for (int q = 0; q < 4 && j * 4 + q < n; ++q) out[j * 4 + q] = z[q];
     }
 }
 EXPORT void or_philox_uniforms(uint64_t seed, uint32_t patient, uint32_t l, uint32_t tag, int n, float *out) {
-    for (int j = 0; j * 4 < n; ++j) {
-        uint32_t r[4];
+    /* five 24-bit fields per 128-bit block, most significant first (timediff_amd/csrc/rng.h td_uniform5) */
+    for (int j = 0; j * 5 < n; ++j) {
+        uint32_t r[4], f[5];
         philox4x32_10(patient, l, tag, 0x10000u + (uint32_t)j, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-        for (int q = 0; q < 4 && j * 4 + q < n; ++q) out[j * 4 + q] = u32_to_unit(r[q]);
+        f[0] = r[0] >> 8;
+        f[1] = ((r[0] & 0xFFu) << 16) | (r[1] >> 16);
+        f[2] = ((r[1] & 0xFFFFu) << 8) | (r[2] >> 24);
+        f[3] = r[2] & 0xFFFFFFu;
+        f[4] = r[3] >> 8;
+        for (int q = 0; q < 5 && j * 5 + q < n; ++q) out[j * 5 + q] = (float)f[q] * (1.0f / 16777216.0f);
     }
 }
 

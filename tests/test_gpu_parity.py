@@ -377,3 +377,116 @@ def test_chain_teacher_forced_margin_gate(name, dev):
     if total:
         print(f"\n[{name}] positions under the Gumbel margin: {below}/{total} = {below / total:.4f}; "
               f"indices differing from the reference there: {flips}")
+
+
+# ---------------------------------------------------------------------------------------------
+# posterior terms of the fused reverse update, exposed for parity (td_reverse_step_terms)
+# ---------------------------------------------------------------------------------------------
+def _slice_shift_removed(a, K):
+    """log theta with each variable's per-position mean removed: the reference normalises with differences of a
+    cumulative logsumexp (mixed_diffusion.py:32-42), whose error is a per-slice SHIFT."""
+    out, off = a.copy(), 0
+    for k in K:
+        out[:, off:off + k] -= out[:, off:off + k].mean(axis=1, keepdims=True)
+        off += k
+    return out
+
+
+@pytest.mark.parametrize("name", ["eicu", "k3mix"])
+def test_reverse_step_posterior_terms(name, dev):
+    """x0 (post-clamp), posterior mean and log theta of the fused kernel against the reference's recorded terms at
+    t in {999 ... 0}: fp32 1e-5 on the Gaussian terms; log theta against the oracle's direct per-slice form 2e-5, and
+    against the reference after removing the per-slice shift of its cumulative logsumexp: 1e-3 for t <= 10, 2e-5 above
+    (the within-slice error of the reference's form)."""
+    g = load_golden(f"reverse_steps_{name}_T1000")
+    K = [int(k) for k in g["K"]]
+    dk = diff_kernels(g, 12, 1000, dev)
+    od = orc.Diffusion(len(g["num_idx"]), K, 12, 1000)
+    for i in g["steps"]:
+        p = f"t{i}."
+        x0, mean, lth = dk.reverse_step_terms(cu(g[p + "model_out"], dev), cu(g[p + "z"], dev), cu(g[p + "idx"], dev), int(i))
+        np.testing.assert_allclose(x0.cpu().numpy(), g[p + "x0"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(mean.cpu().numpy(), g[p + "mean"], rtol=1e-5, atol=1e-5)
+        _, _, det = od.reverse_step(g[p + "model_out"], g[p + "z"], g[p + "idx"], int(i), g[p + "noise"], g[p + "uniforms"],
+                                    details=True)
+        lth = lth.cpu().numpy()
+        live = det["log_theta"] > -60          # entries at the 1e-30 floor carry no information
+        np.testing.assert_allclose(lth[live], det["log_theta"][live], rtol=0, atol=2e-5)
+        ref = g[p + "log_theta"]
+        tol = 1e-3 if i <= 10 else 2e-5
+        d = np.abs(_slice_shift_removed(lth, K) - _slice_shift_removed(ref, K))
+        live_ref = (ref > -60) & live
+        # a floor entry inside a slice moves that slice's mean: compare slices that are fully live
+        ok, off = np.ones(ref.shape, bool), 0
+        for k in K:
+            ok[:, off:off + k] = live_ref[:, off:off + k].all(axis=1, keepdims=True)
+            off += k
+        assert d[ok].max() < tol, (int(i), float(d[ok].max()))
+
+
+def test_many_classes_and_scalar_path(dev):
+    """Variables with more than 8 classes (the reference takes any K_i, mixed_diffusion.py:44-51) run the scalar
+    kernels; a sequence length that is not a multiple of 4 does too.  q_sample, reverse update and loss against the
+    oracle at K = [12, 3, 2], L = 10 and L = 12."""
+    K, n_num, T = [12, 3, 2], 3, 50
+    tables = orc.schedule(T, "cosine")
+    rng = np.random.default_rng(5)
+    from timediff_amd.ops import DiffusionKernels
+    for L in (10, 12):
+        B = 9
+        C = n_num + len(K)
+        dk = DiffusionKernels([0, 2, 4], [1, 3, 5], K, L, T, {k: torch.from_numpy(v) for k, v in tables.items()}, C, dev)
+        od = orc.Diffusion(n_num, K, L, T, tables=tables)
+        data = rng.random((B, C, L)).astype(np.float32)
+        for j, k in zip([1, 3, 5], K):
+            data[:, j] = rng.integers(0, k, (B, L))
+        t = rng.integers(0, T, B)
+        t[0], t[1] = 0, T - 1
+        noise = rng.standard_normal((B, n_num, L)).astype(np.float32)
+        uni = rng.random((B, sum(K), L), dtype=np.float32)
+        x_in, x0_idx, xt_idx, _ = dk.q_sample(cu(data, dev), cu(t, dev), cu(noise, dev), cu(uni, dev))
+        x_ref, xt_ref = od.q_sample(data[:, [0, 2, 4]] * 2 - 1, data[:, [1, 3, 5]].astype(np.uint8), t, noise, uni)
+        np.testing.assert_allclose(x_in.cpu().numpy(), x_ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(xt_idx.cpu().numpy(), xt_ref)
+        mo = rng.standard_normal((B, n_num + sum(K), L)).astype(np.float32) * 2
+        ref = od.mixed_loss(mo, noise, x0_idx.cpu().numpy(), xt_ref, t, 0.8)
+        loss, grad = dk.mixed_loss(cu(mo, dev), cu(noise, dev), x0_idx, xt_idx, cu(t, dev), 0.8)
+        np.testing.assert_allclose(loss.item(), ref["loss"], rtol=2e-5)
+        np.testing.assert_allclose(grad.cpu().numpy(), ref["grad"], rtol=1e-4, atol=1e-5 * float(np.abs(ref["grad"]).max()))
+        for step in (T - 1, 7, 0):
+            z = rng.standard_normal((B, n_num, L)).astype(np.float32)
+            idx = np.stack([rng.integers(0, k, (B, L)) for k in K], 1).astype(np.uint8)
+            zc, ic = cu(z, dev), cu(idx, dev)
+            dk.reverse_step_(cu(mo, dev), zc, ic, step, cu(noise, dev), cu(uni, dev))
+            z_ref, i_ref, det = od.reverse_step(mo, z, idx, step, noise, uni, details=True)
+            np.testing.assert_allclose(zc.cpu().numpy(), z_ref, rtol=1e-5, atol=1e-5)
+            safe = od.gumbel_margin(det["log_theta"], uni) > 1e-4
+            assert np.array_equal(ic.cpu().numpy()[safe], i_ref[safe]) and safe.mean() > 0.99
+
+
+def test_vector_and_scalar_kernels_agree(dev):
+    """The 4-positions-per-thread kernels and the scalar ones (taken when a pointer is not 16-byte aligned) compute the
+    same thing: identical class ids, continuous outputs equal to the last bit or two."""
+    from timediff_amd.ops import DiffusionKernels
+    K, T, L, B = [2, 2, 3], 1000, 24, 33
+    tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
+    dk = DiffusionKernels([0, 1], [2, 3, 4], K, L, T, tables, 5, dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    mo_pad = torch.randn(B * 9 * L + 1, device=dev, generator=g)
+    outs = []
+    for shift in (0, 1):        # shift 1: a view that starts 4 bytes into the allocation -> scalar kernels
+        mo = mo_pad[shift:shift + B * 9 * L].view(B, 9, L)
+        if shift:
+            mo.copy_(mo_pad[:B * 9 * L].view(B, 9, L).clone())
+        z, idx = dk.prior(B, seed=11)
+        dk.reverse_step_(mo, z, idx, 321, seed=11)
+        noise = torch.randn(B, 2, L, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+        x0 = (idx + 1) % torch.tensor(K, device=dev, dtype=torch.uint8)[None, :, None]
+        t = torch.arange(B, device=dev) * 30 % T
+        loss, grad = dk.mixed_loss(mo, noise, x0, idx, t, 0.8)
+        outs.append((z.clone(), idx.clone(), loss.clone(), grad.clone()))
+        mo_first = mo.clone()
+    (z0, i0, l0, g0), (z1, i1, l1, g1) = outs
+    assert torch.equal(i0, i1)
+    assert torch.allclose(z0, z1, rtol=1e-6, atol=1e-6) and torch.allclose(g0, g1, rtol=1e-5, atol=1e-9)
+    assert abs(l0.item() - l1.item()) <= 1e-6 * abs(l0.item())

@@ -73,6 +73,7 @@ _SIGS = {
     "td_sample_prior": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, Rng, _P, _P, _P]),
     "td_build_denoiser_input": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P]),
     "td_reverse_step_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _I, _P, _P, _P, Rng, _P]),
+    "td_reverse_step_terms": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     "td_decode_samples": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P]),
     "td_sample_chain_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), C.POINTER(DiffusionConfig), _I]),
     "td_sample_chain": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(DiffusionConfig), _P, C.POINTER(_P), _P, _I, _P, _P,

@@ -1,14 +1,19 @@
-// Mixed-diffusion arithmetic as fused elementwise passes (one thread per (sequence, position)).
+// Mixed-diffusion arithmetic as fused elementwise passes.
 // Reference: models/ETDiff/mixed_diffusion.py; n_cat = 0 covers models/ETDiff/gaussian_diffusion.py.
-// All of these kernels are HBM-bound: consecutive lanes walk consecutive positions l of one channel
-// row, so every load/store instruction is a coalesced 256-byte row segment.
+// All of these kernels are HBM-bound streaming passes over channel-major (B, C, L) tensors.  A thread owns VEC = 4
+// consecutive positions l of one sequence for ALL channels (16-byte loads and stores along l, one 32-bit load for
+// four uint8 class ids); the scalar form VEC = 1 takes sequence lengths that are not a multiple of 4 or pointers
+// that are not 16-byte aligned.  Everything that depends only on the step t (and on a variable's class count) is
+// computed once per block (reverse update: every sequence is at the same t) or once per thread and variable
+// (training: t differs per sequence) instead of once per class and position.  Exponentials and logarithms use the
+// hardware forms v_exp_f32 / v_log_f32 (1 ulp) with the base change as one multiply: the deviation from libm's
+// expf / logf is a few 1e-7 absolute on every quantity here, against the 1e-5 tolerance of the parity tests; the
+// Gumbel transform keeps libm's logf (its inner logarithm's RELATIVE error becomes an absolute error of the noise).
 #include "common.h"
+#include "rng.h"
 
-#define TD_KMAX 8  // classes per discrete variable held in registers
-
-struct TdTabs {
-    const float *t[TD_TAB_COUNT];
-};
+#define TD_KMAX 8          // classes per discrete variable on the vectorised path (logits of 4 positions in registers)
+#define TD_KMAX_WIDE 32    // any class count the denoiser width allows (c_out <= 32): scalar path
 
 static int td_check_diff(const td_diffusion_config *c, int batch) {
     TD_REQUIRE(c != nullptr, "td_diffusion_config is NULL");
@@ -19,8 +24,8 @@ static int td_check_diff(const td_diffusion_config *c, int batch) {
     TD_REQUIRE(c->seq_len > 0 && c->timesteps > 0, "seq_len and timesteps must be positive");
     TD_REQUIRE(c->tables != nullptr, "tables is NULL");
     for (int v = 0; v < c->n_cat; ++v)
-        if (c->num_classes[v] < 1 || c->num_classes[v] > TD_KMAX) {
-            td_set_error("num_classes[%d] = %d not in [1, %d]", v, c->num_classes[v], TD_KMAX);
+        if (c->num_classes[v] < 1 || c->num_classes[v] > TD_MAX_CLASSES) {
+            td_set_error("num_classes[%d] = %d not in [1, %d]", v, c->num_classes[v], TD_MAX_CLASSES);
             return TD_ERR_UNSUPPORTED;
         }
     TD_REQUIRE(c->data_channels >= 1, "data_channels must be positive");
@@ -36,84 +41,191 @@ static inline int td_sum_k(const td_diffusion_config *c) {
     for (int v = 0; v < c->n_cat; ++v) s += c->num_classes[v];
     return s;
 }
+static inline int td_max_k(const td_diffusion_config *c) {
+    int m = 0;
+    for (int v = 0; v < c->n_cat; ++v) m = c->num_classes[v] > m ? c->num_classes[v] : m;
+    return m;
+}
+static inline bool td_al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 __device__ __forceinline__ float td_tab(const td_diffusion_config &c, int row, int t) {
     return c.tables[(size_t)row * c.timesteps + t];
 }
 
-__device__ __forceinline__ float td_gumbel(float u) { return -logf(-logf(u + 1e-30f) + 1e-30f); }
+// hardware exp / log (v_exp_f32, v_log_f32 are base 2)
+__device__ __forceinline__ float td_fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float td_flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+// log_add_exp (mixed_diffusion.py:20-22): m + log(exp(a - m) + exp(b - m)); the larger argument's term is exp(0) = 1
+__device__ __forceinline__ float td_flae(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m + td_flog(1.0f + td_fexp(fminf(a, b) - m));
+}
+// Gumbel transform (:322-324).  Hardware logarithms: the inner one's relative error (2 ulp) becomes an absolute error of
+// 2.4e-7 of the noise, the outer one adds 2 ulp of |g| <= 17: below 1e-6 wherever it matters, against the 1e-5 margin gate
+// of the parity tests.  TD_GUMBEL_FAST = 0 builds libm's logf for both (A/B measurements: 0.189 -> 0.166 ms per launch).
+#ifndef TD_GUMBEL_FAST
+#define TD_GUMBEL_FAST 2
+#endif
+__device__ __forceinline__ float td_gumbel(float u) {
+#if TD_GUMBEL_FAST == 0
+    return -logf(-logf(u + 1e-30f) + 1e-30f);
+#elif TD_GUMBEL_FAST == 1
+    return -td_flog(-logf(u + 1e-30f) + 1e-30f);
+#else
+    return -td_flog(-td_flog(u + 1e-30f) + 1e-30f);
+#endif
+}
 
-// noise source for one (b, l): external arrays or Philox
+// VEC consecutive floats / class ids along l
+template <int VEC>
+struct TdVec {
+    float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ TdVec<VEC> td_ldf(const float *p) {
+    TdVec<VEC> r;
+    if constexpr (VEC == 4) {
+        const f32x4 q = *(const f32x4 *)p;
+        r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q[2]; r.v[3] = q[3];
+    } else {
+        r.v[0] = p[0];
+    }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void td_stf(float *p, const TdVec<VEC> &r) {
+    if constexpr (VEC == 4) {
+        f32x4 q = {r.v[0], r.v[1], r.v[2], r.v[3]};
+        *(f32x4 *)p = q;
+    } else {
+        p[0] = r.v[0];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void td_ldb(const uint8_t *p, int out[VEC]) {
+    if constexpr (VEC == 4) {
+        const uint32_t q = *(const uint32_t *)p;
+        out[0] = q & 255; out[1] = (q >> 8) & 255; out[2] = (q >> 16) & 255; out[3] = q >> 24;
+    } else {
+        out[0] = p[0];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void td_stb(uint8_t *p, const int in[VEC]) {
+    if constexpr (VEC == 4) *(uint32_t *)p = (uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24);
+    else p[0] = (uint8_t)in[0];
+}
+
+// Noise source of VEC consecutive positions of one sequence: external arrays or Philox (the counter layout is keyed
+// by (patient, position, tag, 4-channel block), so each position makes its own calls whatever VEC is).
+template <int VEC>
 struct TdDraw {
     const float *noise, *uniforms;
     uint64_t seed;
-    uint32_t patient, l, tag;
-    size_t nbase, ubase;  // offsets of (b, channel 0, l)
+    uint32_t patient, l0, tag;
+    size_t nbase, ubase;  // offsets of (b, channel 0, l0)
     int L;
-    float nbuf[4], ubuf[4];
+    float nbuf[VEC][4], ubuf[VEC][TD_UNI_PER_BLOCK];
     int nblk, ublk;
-    __device__ TdDraw(const float *n, const float *u, td_rng rng, int b, int l_, int n_num, int sumk, int L_, uint32_t tag_)
-        : noise(n), uniforms(u), seed(rng.seed), patient(rng.patient0 + (uint32_t)b), l((uint32_t)l_), tag(tag_),
-          nbase(((size_t)b * n_num) * L_ + l_), ubase(((size_t)b * sumk) * L_ + l_), L(L_), nblk(-1), ublk(-1) {}
-    __device__ float normal(int ch) {
-        if (noise) return noise[nbase + (size_t)ch * L];
-        if ((ch >> 2) != nblk) { nblk = ch >> 2; td_normal4(seed, patient, l, tag, (uint32_t)nblk, nbuf); }
-        const int e = ch & 3;
-        return e == 0 ? nbuf[0] : e == 1 ? nbuf[1] : e == 2 ? nbuf[2] : nbuf[3];
+    __device__ TdDraw(const float *n, const float *u, td_rng rng, int b, int l0_, int n_num, int sumk, int L_, uint32_t tag_)
+        : noise(n), uniforms(u), seed(rng.seed), patient(rng.patient0 + (uint32_t)b), l0((uint32_t)l0_), tag(tag_),
+          nbase(((size_t)b * n_num) * L_ + l0_), ubase(((size_t)b * sumk) * L_ + l0_), L(L_), nblk(-1), ublk(-1) {}
+    __device__ TdVec<VEC> normal(int ch) {
+        if (noise) return td_ldf<VEC>(noise + nbase + (size_t)ch * L);
+        if ((ch >> 2) != nblk) {
+            nblk = ch >> 2;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) td_normal4(seed, patient, l0 + e, tag, (uint32_t)nblk, nbuf[e]);
+        }
+        const int q = ch & 3;
+        TdVec<VEC> r;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.v[e] = q == 0 ? nbuf[e][0] : q == 1 ? nbuf[e][1] : q == 2 ? nbuf[e][2] : nbuf[e][3];
+        return r;
     }
-    __device__ float uniform(int slot) {
-        if (uniforms) return uniforms[ubase + (size_t)slot * L];
-        if ((slot >> 2) != ublk) { ublk = slot >> 2; td_uniform4(seed, patient, l, tag, (uint32_t)ublk, ubuf); }
-        const int e = slot & 3;
-        return e == 0 ? ubuf[0] : e == 1 ? ubuf[1] : e == 2 ? ubuf[2] : ubuf[3];
+    __device__ TdVec<VEC> uniform(int slot) {
+        if (uniforms) return td_ldf<VEC>(uniforms + ubase + (size_t)slot * L);
+        const int blk = slot / TD_UNI_PER_BLOCK, q = slot % TD_UNI_PER_BLOCK;
+        if (blk != ublk) {
+            ublk = blk;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) td_uniform5(seed, patient, l0 + e, tag, (uint32_t)ublk, ubuf[e]);
+        }
+        TdVec<VEC> r;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            r.v[e] = q == 0 ? ubuf[e][0] : q == 1 ? ubuf[e][1] : q == 2 ? ubuf[e][2] : q == 3 ? ubuf[e][3] : ubuf[e][4];
+        return r;
     }
 };
+
+#ifndef TD_GRID_CAP
+#define TD_GRID_CAP 65535
+#endif
+static inline int td_grid(size_t total, int cap = TD_GRID_CAP) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
 
 // ---------------------------------------------------------------------------------------------
 // forward noising for a training batch (mixed_diffusion.py:403-409, :375-387)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void td_q_sample_kernel(td_diffusion_config c, int B, int sumk, const float *data,
-                                                          const int64_t *t, const float *noise, const float *uniforms,
-                                                          td_rng rng, float *x_in, uint8_t *x0_idx, uint8_t *xt_idx,
-                                                          float *noise_out) {
-    const int L = c.seq_len, C_io = c.n_num + sumk;
-    const size_t total = (size_t)B * L;
+template <int VEC>
+__global__ __launch_bounds__(256) void td_q_sample_kernel(td_diffusion_config c, int B, int sumk, const float *__restrict__ data,
+                                                          const int64_t *__restrict__ t, const float *noise, const float *uniforms,
+                                                          td_rng rng, float *__restrict__ x_in, uint8_t *__restrict__ x0_idx,
+                                                          uint8_t *__restrict__ xt_idx, float *__restrict__ noise_out) {
+    const int L = c.seq_len, C_io = c.n_num + sumk, LQ = L / VEC;
+    const size_t total = (size_t)B * LQ;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / L), l = (int)(i % L);
+        const int b = (int)(i / LQ), l0 = (int)(i % LQ) * VEC;
         const int tb = (int)t[b];
-        TdDraw draw(noise, uniforms, rng, b, l, c.n_num, sumk, L, rng.tag);
+        TdDraw<VEC> draw(noise, uniforms, rng, b, l0, c.n_num, sumk, L, rng.tag);
         const float sa = td_tab(c, TD_TAB_SQRT_AC, tb), s1 = td_tab(c, TD_TAB_SQRT_1M_AC, tb);
         for (int ch = 0; ch < c.n_num; ++ch) {
-            const float x0 = data[((size_t)b * c.data_channels + c.num_index[ch]) * L + l] * 2.0f - 1.0f;  // :189-194
-            const float eps = draw.normal(ch);
-            x_in[((size_t)b * C_io + ch) * L + l] = sa * x0 + s1 * eps;  // :240-248
-            if (noise_out) noise_out[((size_t)b * c.n_num + ch) * L + l] = eps;
+            const TdVec<VEC> d = td_ldf<VEC>(data + ((size_t)b * c.data_channels + c.num_index[ch]) * L + l0);
+            const TdVec<VEC> eps = draw.normal(ch);
+            TdVec<VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.v[e] = sa * (d.v[e] * 2.0f - 1.0f) + s1 * eps.v[e];  // :189-194, :240-248
+            td_stf<VEC>(x_in + ((size_t)b * C_io + ch) * L + l0, o);
+            if (noise_out) td_stf<VEC>(noise_out + ((size_t)b * c.n_num + ch) * L + l0, eps);
         }
         const float lca = td_tab(c, TD_TAB_LOG_CUM_ALPHA, tb), l1mca = td_tab(c, TD_TAB_LOG_1M_CUM_ALPHA, tb);
-        int off = 0;
+        int off = 0, lastK = -1;
+        float lg_hit = 0.f, lg_miss = 0.f;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
-            const float logK = logf((float)K);
-            const int x0 = (int)data[((size_t)b * c.data_channels + c.cat_index[v]) * L + l];
-            int best = 0;
-            float bv = -INFINITY;
-            for (int k = 0; k < K; ++k) {
-                const float lx = k == x0 ? 0.f : TD_LOG_1E30;
-                const float logit = td_log_add_exp(lx + lca, l1mca - logK);  // :264-272
-                const float val = td_gumbel(draw.uniform(off + k)) + logit;  // :322-324
-                if (val > bv) { bv = val; best = k; }
+            if (K != lastK) {   // q(x_t | x_0) takes two values per class count (:264-272): the class of x_0 or not
+                lastK = K;
+                const float uni = l1mca - logf((float)K);
+                lg_hit = td_flae(0.f + lca, uni);
+                lg_miss = td_flae(TD_LOG_1E30 + lca, uni);
             }
-            x0_idx[((size_t)b * c.n_cat + v) * L + l] = (uint8_t)x0;
-            xt_idx[((size_t)b * c.n_cat + v) * L + l] = (uint8_t)best;
-            for (int k = 0; k < K; ++k) x_in[((size_t)b * C_io + c.n_num + off + k) * L + l] = k == best ? 0.f : TD_LOG_1E30;
+            const TdVec<VEC> dv = td_ldf<VEC>(data + ((size_t)b * c.data_channels + c.cat_index[v]) * L + l0);
+            int x0[VEC], best[VEC];
+            float bv[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { x0[e] = (int)dv.v[e]; best[e] = 0; bv[e] = -INFINITY; }
+            for (int k = 0; k < K; ++k) {
+                const TdVec<VEC> u = draw.uniform(off + k);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float val = td_gumbel(u.v[e]) + (k == x0[e] ? lg_hit : lg_miss);  // :322-324
+                    if (val > bv[e]) { bv[e] = val; best[e] = k; }
+                }
+            }
+            td_stb<VEC>(x0_idx + ((size_t)b * c.n_cat + v) * L + l0, x0);
+            td_stb<VEC>(xt_idx + ((size_t)b * c.n_cat + v) * L + l0, best);
+            for (int k = 0; k < K; ++k) {
+                TdVec<VEC> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.v[e] = k == best[e] ? 0.f : TD_LOG_1E30;
+                td_stf<VEC>(x_in + ((size_t)b * C_io + c.n_num + off + k) * L + l0, o);
+            }
             off += K;
         }
     }
-}
-
-static inline int td_grid(size_t total, int cap = 4096) {
-    size_t b = (total + 255) / 256;
-    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
 }
 
 extern "C" int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, const float *data, const int64_t *t,
@@ -123,8 +235,15 @@ extern "C" int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, 
     if (rc != TD_OK) return rc;
     TD_REQUIRE(data && t && x_in, "NULL argument");
     TD_REQUIRE(cfg->n_cat == 0 || (x0_idx && xt_idx), "x0_idx / xt_idx required when n_cat > 0");
-    hipLaunchKernelGGL(td_q_sample_kernel, dim3(td_grid((size_t)batch * cfg->seq_len)), dim3(256), 0, (hipStream_t)stream,
-                       *cfg, batch, td_sum_k(cfg), data, t, noise, uniforms, rng, x_in, x0_idx, xt_idx, noise_out);
+    const bool vec = cfg->seq_len % 4 == 0 && td_al16(data) && td_al16(noise) && td_al16(uniforms) && td_al16(x_in) &&
+                     td_al16(noise_out) && ((uintptr_t)x0_idx & 3) == 0 && ((uintptr_t)xt_idx & 3) == 0;
+    const int sumk = td_sum_k(cfg);
+    if (vec)
+        hipLaunchKernelGGL(td_q_sample_kernel<4>, dim3(td_grid((size_t)batch * cfg->seq_len / 4)), dim3(256), 0, (hipStream_t)stream,
+                           *cfg, batch, sumk, data, t, noise, uniforms, rng, x_in, x0_idx, xt_idx, noise_out);
+    else
+        hipLaunchKernelGGL(td_q_sample_kernel<1>, dim3(td_grid((size_t)batch * cfg->seq_len)), dim3(256), 0, (hipStream_t)stream,
+                           *cfg, batch, sumk, data, t, noise, uniforms, rng, x_in, x0_idx, xt_idx, noise_out);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
@@ -132,86 +251,190 @@ extern "C" int td_q_sample_mixed(const td_diffusion_config *cfg, int32_t batch, 
 // ---------------------------------------------------------------------------------------------
 // reverse update (mixed_diffusion.py:412-423, :307-311)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void td_reverse_step_kernel(td_diffusion_config c, int B, int sumk, const float *mo,
-                                                              float *z, uint8_t *idx, int t_host, const int32_t *t_dev,
-                                                              const float *noise, const float *uniforms,
-                                                              size_t noise_stride, size_t uni_stride, td_rng rng) {
-    const int L = c.seq_len, C_io = c.n_num + sumk, T = c.timesteps;
-    const int t = t_dev ? t_dev[0] : t_host;
+struct TdRevParams {
+    td_diffusion_config c;
+    int B, sumk, t_host;
+    const float *mo;
+    float *z;
+    uint8_t *idx;
+    const int32_t *t_dev;
+    const float *noise, *uniforms;
+    size_t noise_stride, uni_stride;
+    td_rng rng;
+    // TERMS kernels only (parity): the posterior terms of the step; nothing is sampled or updated
+    float *x0_out, *mean_out, *log_theta_out;
+};
+
+// three waves per SIMD (138 registers, no spills).  Measured A/B in one process at B = 16 384, L = 272 (0.164-0.172 ms per
+// launch = 2.5-2.7 TB/s): 3 vs 4 waves per SIMD (the latter spills 60 B per lane) and a capped vs one-item-per-thread grid
+// are within the run-to-run noise of each other; what holds the kernel is its integer and transcendental work (3 Philox4x32-10
+// calls, 2 Box-Muller pairs, 30 logs / exps per position ~ 0.1 ms of VALU issue at this size), not HBM.
+#ifndef TD_REV_WAVES
+#define TD_REV_WAVES 3
+#endif
+template <int VEC, int KM, bool TERMS>
+__global__ __launch_bounds__(256, TD_REV_WAVES) void td_reverse_step_kernel(TdRevParams p) {
+    const td_diffusion_config &c = p.c;
+    // per variable: {log K, log q(x_t | x_{t-1}) for the current class, for another class, log((1 - abar_{t-1}) / K)}
+    __shared__ float s_var[TD_MAX_CAT][4];
+    const int L = c.seq_len, C_io = c.n_num + p.sumk, T = c.timesteps, LQ = L / VEC;
+    const int t = p.t_dev ? p.t_dev[0] : p.t_host;
     if (t < 0 || t >= T) return;
+    const float *noise = p.noise, *uniforms = p.uniforms;
     // chained external draws: slab 0 is the prior, slab T - t belongs to step t
-    if (noise && noise_stride) noise += (size_t)(T - t) * noise_stride;
-    if (uniforms && uni_stride) uniforms += (size_t)(T - t) * uni_stride;
+    if (noise && p.noise_stride) noise += (size_t)(T - t) * p.noise_stride;
+    if (uniforms && p.uni_stride) uniforms += (size_t)(T - t) * p.uni_stride;
     const float c_recip = td_tab(c, TD_TAB_SQRT_RECIP_AC, t), c_recipm1 = td_tab(c, TD_TAB_SQRT_RECIPM1_AC, t);
     const float c1 = td_tab(c, TD_TAB_POST_C1, t), c2 = td_tab(c, TD_TAB_POST_C2, t);
     const float sigma = expf(0.5f * td_tab(c, TD_TAB_POST_LOGVAR, t));
     const int tm1 = t > 0 ? t - 1 : 0;
     const float lca = td_tab(c, TD_TAB_LOG_CUM_ALPHA, tm1), l1mca = td_tab(c, TD_TAB_LOG_1M_CUM_ALPHA, tm1);
-    const float la = td_tab(c, TD_TAB_LOG_ALPHA, t), l1ma = td_tab(c, TD_TAB_LOG_1M_ALPHA, t);
-    const size_t total = (size_t)B * L;
+    if ((int)threadIdx.x < c.n_cat) {
+        const float la = td_tab(c, TD_TAB_LOG_ALPHA, t), l1ma = td_tab(c, TD_TAB_LOG_1M_ALPHA, t);
+        const float logK = logf((float)c.num_classes[threadIdx.x]);
+        s_var[threadIdx.x][0] = logK;
+        s_var[threadIdx.x][1] = td_flae(0.f + la, l1ma - logK);            // :255-262
+        s_var[threadIdx.x][2] = td_flae(TD_LOG_1E30 + la, l1ma - logK);
+        s_var[threadIdx.x][3] = l1mca - logK;
+    }
+    __syncthreads();
+    const size_t total = (size_t)p.B * LQ;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / L), l = (int)(i % L);
-        TdDraw draw(noise, uniforms, rng, b, l, c.n_num, sumk, L, (uint32_t)t);
+        const int b = (int)(i / LQ), l0 = (int)(i % LQ) * VEC;
+        TdDraw<VEC> draw(noise, uniforms, p.rng, b, l0, c.n_num, p.sumk, L, (uint32_t)t);
         for (int ch = 0; ch < c.n_num; ++ch) {
-            const size_t zi = ((size_t)b * c.n_num + ch) * L + l;
-            const float eps = mo[((size_t)b * C_io + ch) * L + l], zt = z[zi];
-            float x0 = c_recip * zt - c_recipm1 * eps;          // :196-201
-            x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                  // :234-235
-            const float mean = c1 * x0 + c2 * zt;                // :210-218
-            const float nz = t > 0 ? draw.normal(ch) : 0.f;      // :421
-            z[zi] = mean + sigma * nz;                            // :422
+            const size_t zi = ((size_t)b * c.n_num + ch) * L + l0;
+            const TdVec<VEC> eps = td_ldf<VEC>(p.mo + ((size_t)b * C_io + ch) * L + l0), zt = td_ldf<VEC>(p.z + zi);
+            TdVec<VEC> x0, mean, o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                x0.v[e] = fminf(fmaxf(c_recip * zt.v[e] - c_recipm1 * eps.v[e], -1.0f), 1.0f);   // :196-201, :234-235
+                mean.v[e] = c1 * x0.v[e] + c2 * zt.v[e];                                          // :210-218
+            }
+            if constexpr (TERMS) {
+                td_stf<VEC>(p.x0_out + zi, x0);
+                td_stf<VEC>(p.mean_out + zi, mean);
+            } else {
+                if (t > 0) {                                                                       // :421-422
+                    const TdVec<VEC> nz = draw.normal(ch);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o.v[e] = mean.v[e] + sigma * nz.v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o.v[e] = mean.v[e] + sigma * 0.f;
+                }
+                td_stf<VEC>(p.z + zi, o);
+            }
         }
         int off = 0;
-        // q(x_t | x_{t-1}) in log space (:255-262) takes two values per class count: the current class or not
-        int lastK = -1;
-        float logK = 0.f, w_hit = 0.f, w_miss = 0.f;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
-            if (K != lastK) {
-                lastK = K;
-                logK = logf((float)K);
-                w_hit = td_log_add_exp(0.f + la, l1ma - logK);
-                w_miss = td_log_add_exp(TD_LOG_1E30 + la, l1ma - logK);
-            }
-            const float *zp = mo + ((size_t)b * C_io + c.n_num + off) * L + l;
-            float logit[TD_KMAX];
-            float m = -INFINITY;
+            const float w_hit = s_var[v][1], w_miss = s_var[v][2], uni = s_var[v][3];
+            const float *zp = p.mo + ((size_t)b * C_io + c.n_num + off) * L + l0;
+            float logit[KM][VEC], m[VEC], se[VEC];
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) {
-                logit[k] = k < K ? zp[(size_t)k * L] : -INFINITY;
-                m = fmaxf(m, logit[k]);
-            }
-            float se = 0.f;
+            for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; se[e] = 0.f; }
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) se += k < K ? expf(logit[k] - m) : 0.f;
-            const float lse = m + logf(se);                      // :274-281
-            const int xt = idx[((size_t)b * c.n_cat + v) * L + l];
-            int best = 0;
-            float bv = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) {
+            for (int k = 0; k < KM; ++k) {
                 if (k < K) {
-                    const float lx0 = logit[k] - lse;
-                    const float ev = t == 0 ? lx0 : td_log_add_exp(lx0 + lca, l1mca - logK);   // :284-290
-                    const float w = k == xt ? w_hit : w_miss;
-                    // the per-slice normaliser (:293) shifts all K values equally: argmax-invariant
-                    const float val = td_gumbel(draw.uniform(off + k)) + (ev + w);
-                    if (val > bv) { bv = val; best = k; }
+                    const TdVec<VEC> q = td_ldf<VEC>(zp + (size_t)k * L);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { logit[k][e] = q.v[e]; m[e] = fmaxf(m[e], q.v[e]); }
                 }
             }
-            idx[((size_t)b * c.n_cat + v) * L + l] = (uint8_t)best;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) se[e] += td_fexp(logit[k][e] - m[e]);
+                }
+            int xt[VEC], best[VEC];
+            float bv[VEC], lse[VEC];
+            td_ldb<VEC>(p.idx + ((size_t)b * c.n_cat + v) * L + l0, xt);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { lse[e] = m[e] + td_flog(se[e]); best[e] = 0; bv[e] = -INFINITY; }   // :274-281
+            // log pi + log w per class (the per-slice normaliser of :293 shifts all K values equally: argmax-invariant)
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float lx0 = logit[k][e] - lse[e];
+                        const float ev = t == 0 ? lx0 : td_flae(lx0 + lca, uni);                  // :284-290
+                        logit[k][e] = ev + (k == xt[e] ? w_hit : w_miss);
+                    }
+                }
+            if constexpr (TERMS) {
+                float mm[VEC], ss[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { mm[e] = -INFINITY; ss[e] = 0.f; }
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) mm[e] = fmaxf(mm[e], logit[k][e]);
+                    }
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) ss[e] += td_fexp(logit[k][e] - mm[e]);
+                    }
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        TdVec<VEC> o;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) o.v[e] = logit[k][e] - (mm[e] + td_flog(ss[e]));   // :291-293, direct per-slice LSE
+                        td_stf<VEC>(p.log_theta_out + ((size_t)b * p.sumk + off + k) * L + l0, o);
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        const TdVec<VEC> u = draw.uniform(off + k);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float val = td_gumbel(u.v[e]) + logit[k][e];                    // :322-324
+                            if (val > bv[e]) { bv[e] = val; best[e] = k; }
+                        }
+                    }
+                td_stb<VEC>(p.idx + ((size_t)b * c.n_cat + v) * L + l0, best);
+            }
             off += K;
         }
     }
 }
 
+template <bool TERMS>
+static int td_launch_reverse(const TdRevParams &p, hipStream_t stream) {
+    const td_diffusion_config *cfg = &p.c;
+    bool vec = cfg->seq_len % 4 == 0 && td_al16(p.mo) && td_al16(p.z) && ((uintptr_t)p.idx & 3) == 0 && td_al16(p.noise) &&
+               td_al16(p.uniforms) && p.noise_stride % 4 == 0 && p.uni_stride % 4 == 0 && td_al16(p.x0_out) &&
+               td_al16(p.mean_out) && td_al16(p.log_theta_out);
+    const size_t BL = (size_t)p.B * cfg->seq_len;
+    // binary variables (every dataset of the reference, etdiff_train.py:24-29) get their own instantiation: the class
+    // loops are unrolled to the bound, and 8 classes x 4 positions of logits cost 100 registers more than 2 x 4
+    if (td_max_k(cfg) > TD_KMAX)
+        hipLaunchKernelGGL((td_reverse_step_kernel<1, TD_KMAX_WIDE, TERMS>), dim3(td_grid(BL)), dim3(256), 0, stream, p);
+    else if (vec && td_max_k(cfg) <= 2)
+        hipLaunchKernelGGL((td_reverse_step_kernel<4, 2, TERMS>), dim3(td_grid(BL / 4)), dim3(256), 0, stream, p);
+    else if (vec)
+        hipLaunchKernelGGL((td_reverse_step_kernel<4, TD_KMAX, TERMS>), dim3(td_grid(BL / 4)), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((td_reverse_step_kernel<1, TD_KMAX, TERMS>), dim3(td_grid(BL)), dim3(256), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
                            const int32_t *t_dev, const float *noise, const float *uniforms, size_t noise_stride,
                            size_t uni_stride, td_rng rng, hipStream_t stream) {
-    hipLaunchKernelGGL(td_reverse_step_kernel, dim3(td_grid((size_t)batch * cfg->seq_len)), dim3(256), 0, stream, *cfg,
-                       batch, td_sum_k(cfg), mo, z, idx, t_host, t_dev, noise, uniforms, noise_stride, uni_stride, rng);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+    TdRevParams p;
+    p.c = *cfg; p.B = batch; p.sumk = td_sum_k(cfg); p.t_host = t_host; p.mo = mo; p.z = z; p.idx = idx; p.t_dev = t_dev;
+    p.noise = noise; p.uniforms = uniforms; p.noise_stride = noise_stride; p.uni_stride = uni_stride; p.rng = rng;
+    p.x0_out = p.mean_out = p.log_theta_out = nullptr;
+    return td_launch_reverse<false>(p, stream);
 }
 
 extern "C" int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t batch, const float *model_out, float *z,
@@ -225,119 +448,165 @@ extern "C" int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t bat
                                   (hipStream_t)stream);
 }
 
+extern "C" int td_reverse_step_terms(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *z,
+                                     const uint8_t *idx, int32_t t, float *x0, float *mean, float *log_theta, void *stream) {
+    int rc = td_check_diff(cfg, batch);
+    if (rc != TD_OK) return rc;
+    TD_REQUIRE(model_out && (z || cfg->n_num == 0) && (idx || cfg->n_cat == 0), "NULL argument");
+    TD_REQUIRE((cfg->n_num == 0 || (x0 && mean)) && (cfg->n_cat == 0 || log_theta), "NULL output");
+    TD_REQUIRE(t >= 0 && t < cfg->timesteps, "t = %d outside [0, %d)", t, cfg->timesteps);
+    TdRevParams p;
+    p.c = *cfg; p.B = batch; p.sumk = td_sum_k(cfg); p.t_host = t; p.mo = model_out; p.z = (float *)z; p.idx = (uint8_t *)idx;
+    p.t_dev = nullptr; p.noise = nullptr; p.uniforms = nullptr; p.noise_stride = 0; p.uni_stride = 0;
+    p.rng.seed = 0; p.rng.patient0 = 0; p.rng.tag = 0;
+    p.x0_out = x0; p.mean_out = mean; p.log_theta_out = log_theta;
+    return td_launch_reverse<true>(p, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // loss + gradient (mixed_diffusion.py:390-401)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void td_mixed_loss_kernel(td_diffusion_config c, int B, int sumk, const float *mo,
-                                                            const float *noise, const uint8_t *x0_idx,
-                                                            const uint8_t *xt_idx, const int64_t *t, float lambda,
-                                                            float gscale, float *grad, double *partial) {
-    const int L = c.seq_len, C_io = c.n_num + sumk, T = c.timesteps;
-    const size_t total = (size_t)B * L;
+template <int VEC, int KM>
+__global__ __launch_bounds__(256) void td_mixed_loss_kernel(td_diffusion_config c, int B, int sumk, const float *__restrict__ mo,
+                                                            const float *__restrict__ noise, const uint8_t *__restrict__ x0_idx,
+                                                            const uint8_t *__restrict__ xt_idx, const int64_t *__restrict__ t,
+                                                            float lambda, float gscale, float *__restrict__ grad, double *partial) {
+    const int L = c.seq_len, C_io = c.n_num + sumk, T = c.timesteps, LQ = L / VEC;
+    const size_t total = (size_t)B * LQ;
     const float w_gauss = c.n_num > 0 ? 1.0f / ((float)B * c.n_num * L) : 0.f;
     const float w_multi = c.n_cat > 0 ? lambda / ((float)B * c.n_cat) : 0.f;
     const float lcaT = td_tab(c, TD_TAB_LOG_CUM_ALPHA, T - 1), l1mcaT = td_tab(c, TD_TAB_LOG_1M_CUM_ALPHA, T - 1);
     double local = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / L), l = (int)(i % L);
+        const int b = (int)(i / LQ), l0 = (int)(i % LQ) * VEC;
         const int tb = (int)t[b];
         float sq = 0.f;
         for (int ch = 0; ch < c.n_num; ++ch) {
-            const float d = mo[((size_t)b * C_io + ch) * L + l] - noise[((size_t)b * c.n_num + ch) * L + l];
-            sq += d * d;                                                                   // :364-368
-            if (grad) grad[((size_t)b * C_io + ch) * L + l] = gscale * 2.0f * d * w_gauss;
+            const TdVec<VEC> a = td_ldf<VEC>(mo + ((size_t)b * C_io + ch) * L + l0);
+            const TdVec<VEC> n = td_ldf<VEC>(noise + ((size_t)b * c.n_num + ch) * L + l0);
+            TdVec<VEC> g;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float d = a.v[e] - n.v[e];
+                sq += d * d;                                                               // :364-368
+                g.v[e] = gscale * 2.0f * d * w_gauss;
+            }
+            if (grad) td_stf<VEC>(grad + ((size_t)b * C_io + ch) * L + l0, g);
         }
         const int tm1 = tb > 0 ? tb - 1 : 0;
         const float lca = td_tab(c, TD_TAB_LOG_CUM_ALPHA, tm1), l1mca = td_tab(c, TD_TAB_LOG_1M_CUM_ALPHA, tm1);
         const float la = td_tab(c, TD_TAB_LOG_ALPHA, tb), l1ma = td_tab(c, TD_TAB_LOG_1M_ALPHA, tb);
-        const float s_prev = tb == 0 ? 1.0f : expf(lca);
+        const float s_prev = tb == 0 ? 1.0f : td_fexp(lca);
         float term = 0.f, prior = 0.f;
         int off = 0;
-        // q(x_t | x_{t-1}) in log space (:255-262) takes two values per class count: the current class or not
-        // ... and so do the true posterior's q(x_{t-1} | x_0) term and the prior KL (x_0 is exactly one-hot): computed
-        // once per class count instead of once per class -- the same expressions on the same inputs, bit for bit
+        // q(x_t | x_{t-1}) in log space (:255-262) takes two values per class count: the current class or not;
+        // so do the true posterior's q(x_{t-1} | x_0) term and the prior KL (x_0 is exactly one-hot): computed once per
+        // class count and thread instead of once per class and position
         int lastK = -1;
-        float logK = 0.f, w_hit = 0.f, w_miss = 0.f, evt_hit = 0.f, evt_miss = 0.f, prior_hit = 0.f, prior_miss = 0.f;
+        float uni = 0.f, w_hit = 0.f, w_miss = 0.f, evt_hit = 0.f, evt_miss = 0.f, prior_hit = 0.f, prior_miss = 0.f, unif_p = 0.f;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
             if (K != lastK) {
                 lastK = K;
-                logK = logf((float)K);
-                w_hit = td_log_add_exp(0.f + la, l1ma - logK);
-                w_miss = td_log_add_exp(TD_LOG_1E30 + la, l1ma - logK);
-                evt_hit = tb == 0 ? 0.f : td_log_add_exp(0.f + lca, l1mca - logK);
-                evt_miss = tb == 0 ? TD_LOG_1E30 : td_log_add_exp(TD_LOG_1E30 + lca, l1mca - logK);
-                const float lq_hit = td_log_add_exp(0.f + lcaT, l1mcaT - logK), lq_miss = td_log_add_exp(TD_LOG_1E30 + lcaT, l1mcaT - logK);
-                prior_hit = expf(lq_hit) * (lq_hit + logK);                                // :330-339
-                prior_miss = expf(lq_miss) * (lq_miss + logK);
+                const float logK = logf((float)K);
+                uni = l1mca - logK;
+                unif_p = (1.0f - s_prev) / (float)K;
+                w_hit = td_flae(0.f + la, l1ma - logK);
+                w_miss = td_flae(TD_LOG_1E30 + la, l1ma - logK);
+                evt_hit = tb == 0 ? 0.f : td_flae(0.f + lca, uni);
+                evt_miss = tb == 0 ? TD_LOG_1E30 : td_flae(TD_LOG_1E30 + lca, uni);
+                const float lq_hit = td_flae(0.f + lcaT, l1mcaT - logK), lq_miss = td_flae(TD_LOG_1E30 + lcaT, l1mcaT - logK);
+                prior_hit = td_fexp(lq_hit) * (lq_hit + logK);                              // :330-339
+                prior_miss = td_fexp(lq_miss) * (lq_miss + logK);
             }
-            const float *zp = mo + ((size_t)b * C_io + c.n_num + off) * L + l;
-            const int x0 = x0_idx[((size_t)b * c.n_cat + v) * L + l], xt = xt_idx[((size_t)b * c.n_cat + v) * L + l];
-            float lx0h[TD_KMAX], ut[TD_KMAX], um[TD_KMAX];
-            float m = -INFINITY;
+            const float *zp = mo + ((size_t)b * C_io + c.n_num + off) * L + l0;
+            int x0[VEC], xt[VEC];
+            td_ldb<VEC>(x0_idx + ((size_t)b * c.n_cat + v) * L + l0, x0);
+            td_ldb<VEC>(xt_idx + ((size_t)b * c.n_cat + v) * L + l0, xt);
+            float lx0h[KM][VEC], um[KM][VEC];
+            float m[VEC], se[VEC];
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) {
-                lx0h[k] = k < K ? zp[(size_t)k * L] : -INFINITY;
-                m = fmaxf(m, lx0h[k]);
-            }
-            float se = 0.f;
+            for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; se[e] = 0.f; }
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k)
-                if (k < K) se += expf(lx0h[k] - m);
-            const float lse = m + logf(se);
-            float mt = -INFINITY, mm = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) {
+            for (int k = 0; k < KM; ++k)
                 if (k < K) {
-                    lx0h[k] -= lse;                                                        // :274-281
-                    const float w = k == xt ? w_hit : w_miss;
-                    const float evt = k == x0 ? evt_hit : evt_miss;
-                    const float evm = tb == 0 ? lx0h[k] : td_log_add_exp(lx0h[k] + lca, l1mca - logK);
-                    ut[k] = evt + w;
-                    um[k] = evm + w;
-                    mt = fmaxf(mt, ut[k]);
-                    mm = fmaxf(mm, um[k]);
-                    prior += k == x0 ? prior_hit : prior_miss;
-                } else {
-                    ut[k] = -INFINITY; um[k] = -INFINITY;
-                }
-            }
-            float st = 0.f, sm = 0.f;
+                    const TdVec<VEC> q = td_ldf<VEC>(zp + (size_t)k * L);
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k)
-                if (k < K) {
-                    st += expf(ut[k] - mt);
-                    sm += expf(um[k] - mm);
+                    for (int e = 0; e < VEC; ++e) { lx0h[k][e] = q.v[e]; m[e] = fmaxf(m[e], q.v[e]); }
                 }
-            const float lset = mt + logf(st), lsem = mm + logf(sm);  // direct per-slice logsumexp (vs :32-42)
-            float tgt_sum = 0.f, gp = 0.f;
-            float gk[TD_KMAX];
 #pragma unroll
-            for (int k = 0; k < TD_KMAX; ++k) {
+            for (int k = 0; k < KM; ++k)
                 if (k < K) {
-                    const float lt = ut[k] - lset, lm = um[k] - lsem;
-                    const float lx0 = k == x0 ? 0.f : TD_LOG_1E30;
-                    if (tb == 0) term -= expf(lx0) * lm;                                   // :351-352
-                    else term += expf(lt) * (lt - lm);                                     // :348-349
-                    ut[k] = tb == 0 ? expf(lx0) : expf(lt);   // target probability
-                    um[k] = expf(lm);                          // theta
-                    tgt_sum += ut[k];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) se[e] += td_fexp(lx0h[k][e] - m[e]);
                 }
+            float mt[VEC], mm[VEC], st[VEC], sm[VEC], lset[VEC], lsem[VEC], tgt_sum[VEC], gp[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float lse = m[e] + td_flog(se[e]);
+                mt[e] = -INFINITY; mm[e] = -INFINITY; st[e] = 0.f; sm[e] = 0.f; tgt_sum[e] = 0.f; gp[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        lx0h[k][e] -= lse;                                                 // :274-281
+                        const float w = k == xt[e] ? w_hit : w_miss;
+                        const float evm = tb == 0 ? lx0h[k][e] : td_flae(lx0h[k][e] + lca, uni);
+                        um[k][e] = evm + w;
+                        mt[e] = fmaxf(mt[e], (k == x0[e] ? evt_hit : evt_miss) + w);
+                        mm[e] = fmaxf(mm[e], um[k][e]);
+                        prior += k == x0[e] ? prior_hit : prior_miss;
+                    }
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        const float utk = (k == x0[e] ? evt_hit : evt_miss) + (k == xt[e] ? w_hit : w_miss);
+                        st[e] += td_fexp(utk - mt[e]);
+                        sm[e] += td_fexp(um[k][e] - mm[e]);
+                    }
+                lset[e] = mt[e] + td_flog(st[e]);     // direct per-slice logsumexp (vs :32-42)
+                lsem[e] = mm[e] + td_flog(sm[e]);
             }
+            // um[k] <- theta_k; target probability and the loss term
+            float tg[KM][VEC];
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float utk = (k == x0[e] ? evt_hit : evt_miss) + (k == xt[e] ? w_hit : w_miss);
+                        const float lt = utk - lset[e], lm = um[k][e] - lsem[e];
+                        const float p0 = k == x0[e] ? 1.0f : 1e-30f;                        // exp(log x_0), :44-51
+                        const float pt = td_fexp(lt);
+                        if (tb == 0) term -= p0 * lm;                                       // :351-352
+                        else term += pt * (lt - lm);                                        // :348-349
+                        tg[k][e] = tb == 0 ? p0 : pt;
+                        um[k][e] = td_fexp(lm);
+                        tgt_sum[e] += tg[k][e];
+                    }
+                }
             if (grad) {
                 const float scale = gscale * w_multi * (float)T;
 #pragma unroll
-                for (int k = 0; k < TD_KMAX; ++k) {
+                for (int k = 0; k < KM; ++k)
                     if (k < K) {
-                        const float pk = expf(lx0h[k]);
-                        const float pi = tb == 0 ? pk : s_prev * pk + (1.0f - s_prev) / (float)K;
-                        gk[k] = s_prev * (um[k] * tgt_sum - ut[k]) / pi;
-                        gp += gk[k] * pk;
-                    }
-                }
 #pragma unroll
-                for (int k = 0; k < TD_KMAX; ++k)
-                    if (k < K) grad[((size_t)b * C_io + c.n_num + off + k) * L + l] = scale * expf(lx0h[k]) * (gk[k] - gp);
+                        for (int e = 0; e < VEC; ++e) {
+                            const float pk = td_fexp(lx0h[k][e]);
+                            const float pi = tb == 0 ? pk : s_prev * pk + unif_p;
+                            const float gk = s_prev * (um[k][e] * tgt_sum[e] - tg[k][e]) * __builtin_amdgcn_rcpf(pi);
+                            lx0h[k][e] = pk;
+                            tg[k][e] = gk;
+                            gp[e] += gk * pk;
+                        }
+                    }
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        TdVec<VEC> o;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) o.v[e] = scale * lx0h[k][e] * (tg[k][e] - gp[e]);
+                        td_stf<VEC>(grad + ((size_t)b * C_io + c.n_num + off + k) * L + l0, o);
+                    }
             }
             off += K;
         }
@@ -373,6 +642,38 @@ extern "C" size_t td_mixed_loss_workspace_bytes(const td_diffusion_config *, int
     return TD_LOSS_BLOCKS * sizeof(double);
 }
 
+// both loss entry points: the fused loss + gradient pass into `partial`, then the finishing reduction
+static int td_mixed_loss_launch(const td_diffusion_config *cfg, int batch, const float *model_out, const float *noise,
+                                const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t, float loss_lambda, float scale,
+                                float *loss, float *grad, double *partial, hipStream_t stream) {
+    const bool vec = cfg->seq_len % 4 == 0 && td_al16(model_out) && td_al16(noise) && td_al16(grad) && ((uintptr_t)x0_idx & 3) == 0 &&
+                     ((uintptr_t)xt_idx & 3) == 0;
+    const size_t BL = (size_t)batch * cfg->seq_len;
+    const int sumk = td_sum_k(cfg);
+    int blocks;
+    if (td_max_k(cfg) > TD_KMAX) {
+        blocks = td_grid(BL, TD_LOSS_BLOCKS);
+        hipLaunchKernelGGL((td_mixed_loss_kernel<1, TD_KMAX_WIDE>), dim3(blocks), dim3(256), 0, stream, *cfg, batch, sumk, model_out,
+                           noise, x0_idx, xt_idx, t, loss_lambda, scale, grad, partial);
+    } else if (vec && td_max_k(cfg) <= 2) {
+        blocks = td_grid(BL / 4, TD_LOSS_BLOCKS);
+        hipLaunchKernelGGL((td_mixed_loss_kernel<4, 2>), dim3(blocks), dim3(256), 0, stream, *cfg, batch, sumk, model_out, noise,
+                           x0_idx, xt_idx, t, loss_lambda, scale, grad, partial);
+    } else if (vec) {
+        blocks = td_grid(BL / 4, TD_LOSS_BLOCKS);
+        hipLaunchKernelGGL((td_mixed_loss_kernel<4, TD_KMAX>), dim3(blocks), dim3(256), 0, stream, *cfg, batch, sumk, model_out, noise,
+                           x0_idx, xt_idx, t, loss_lambda, scale, grad, partial);
+    } else {
+        blocks = td_grid(BL, TD_LOSS_BLOCKS);
+        hipLaunchKernelGGL((td_mixed_loss_kernel<1, TD_KMAX>), dim3(blocks), dim3(256), 0, stream, *cfg, batch, sumk, model_out, noise,
+                           x0_idx, xt_idx, t, loss_lambda, scale, grad, partial);
+    }
+    TD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(td_loss_finish_kernel, dim3(1), dim3(256), 0, stream, (const double *)partial, blocks, 1.0f, loss);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 extern "C" int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *noise,
                              const uint8_t *x0_idx, const uint8_t *xt_idx, const int64_t *t, float loss_lambda,
                              float scale, float *loss, float *grad, void *workspace, void *stream) {
@@ -381,14 +682,8 @@ extern "C" int td_mixed_loss(const td_diffusion_config *cfg, int32_t batch, cons
     TD_REQUIRE(model_out && t && loss && workspace, "NULL argument");
     TD_REQUIRE(cfg->n_num == 0 || noise, "noise required when n_num > 0");
     TD_REQUIRE(cfg->n_cat == 0 || (x0_idx && xt_idx), "x0_idx / xt_idx required when n_cat > 0");
-    const int blocks = td_grid((size_t)batch * cfg->seq_len, TD_LOSS_BLOCKS);
-    hipLaunchKernelGGL(td_mixed_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *cfg, batch, td_sum_k(cfg),
-                       model_out, noise, x0_idx, xt_idx, t, loss_lambda, scale, grad, (double *)workspace);
-    TD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(td_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)workspace, blocks,
-                       1.0f, loss);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+    return td_mixed_loss_launch(cfg, batch, model_out, noise, x0_idx, xt_idx, t, loss_lambda, scale, loss, grad,
+                                (double *)workspace, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,15 +721,8 @@ extern "C" int td_mixed_loss_noalloc(const td_diffusion_config *cfg, int32_t bat
         TD_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned NULL for the loss scratch");
         g_loss_scratch_ptr[dev] = ptr;
     }
-    double *partial = g_loss_scratch_ptr[dev];
-    const int blocks = td_grid(positions, TD_LOSS_BLOCKS);
-    hipLaunchKernelGGL(td_mixed_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *cfg, batch, td_sum_k(cfg),
-                       model_out, noise, x0_idx, xt_idx, t, loss_lambda, scale, grad, partial);
-    TD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(td_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)partial, blocks,
-                       1.0f, loss);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+    return td_mixed_loss_launch(cfg, batch, model_out, noise, x0_idx, xt_idx, t, loss_lambda, scale, loss, grad,
+                                g_loss_scratch_ptr[dev], (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -446,14 +734,14 @@ __global__ __launch_bounds__(256) void td_prior_kernel(td_diffusion_config c, in
     const size_t total = (size_t)B * L;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / L), l = (int)(i % L);
-        TdDraw draw(noise, uniforms, rng, b, l, c.n_num, sumk, L, (uint32_t)c.timesteps);
-        for (int ch = 0; ch < c.n_num; ++ch) z[((size_t)b * c.n_num + ch) * L + l] = draw.normal(ch);   // :429
+        TdDraw<1> draw(noise, uniforms, rng, b, l, c.n_num, sumk, L, (uint32_t)c.timesteps);
+        for (int ch = 0; ch < c.n_num; ++ch) z[((size_t)b * c.n_num + ch) * L + l] = draw.normal(ch).v[0];   // :429
         int off = 0;
         for (int v = 0; v < c.n_cat; ++v) {   // :434-435: Gumbel-max over all-zero logits
             int best = 0;
             float bv = -INFINITY;
             for (int k = 0; k < c.num_classes[v]; ++k) {
-                const float val = td_gumbel(draw.uniform(off + k)) + 0.0f;
+                const float val = td_gumbel(draw.uniform(off + k).v[0]) + 0.0f;
                 if (val > bv) { bv = val; best = k; }
             }
             idx[((size_t)b * c.n_cat + v) * L + l] = (uint8_t)best;

@@ -230,6 +230,17 @@ class DiffusionKernels:
         check(lib().td_reverse_step_mixed(C.byref(self.cfg), B, ptr(model_out), ptr(z), ptr(idx), int(t), None,
                                           ptr(noise), ptr(uniforms), self._rng(seed, patient0), _stream()))
 
+    def reverse_step_terms(self, model_out, z, idx, t):
+        """-> (x0, mean, log_theta) of the step as the fused kernel computes them (parity aid, nothing is sampled)."""
+        model_out = _f32(model_out)
+        B = model_out.shape[0]
+        x0 = torch.empty(B, self.n_num, self.L, dtype=torch.float32, device=self.device)
+        mean = torch.empty_like(x0)
+        lth = torch.empty(B, self.sumk, self.L, dtype=torch.float32, device=self.device)
+        check(lib().td_reverse_step_terms(C.byref(self.cfg), B, ptr(model_out), ptr(z), ptr(idx), int(t), ptr(x0), ptr(mean),
+                                          ptr(lth), _stream()))
+        return x0, mean, lth
+
     def decode(self, z, idx):
         B = z.shape[0] if self.n_num else idx.shape[0]
         out = torch.empty(B, self.data_channels, self.L, dtype=torch.float32, device=self.device)
