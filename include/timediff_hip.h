@@ -263,15 +263,18 @@ TD_API int td_clip_adam_ema(float *param, const float *grad, float *exp_avg, flo
 /* Kernel-selection knobs for tests and measurements, no counterpart in the reference (process-wide, not
  * thread-safe against concurrent launches).
  *   td_set_layer_kernel: which recurrent-layer kernel family runs hidden sizes <= 256.  AUTO picks by batch
- *     (csrc/rnn.hip td_use_wide: the unit-split kernel of rnn_wide.hip below ~8192 sequences, the
- *     batch-block kernel of rnn_layer.h above); BATCH / UNITS force one family (UNITS needs hidden > 32).
+ *     (csrc/rnn.hip: the cluster-persistent kernel of rnn_cluster.hip up to 512 sequences at hidden 193..256 --
+ *     weights resident in registers, 8 workgroups per 32 sequences exchanging h_t through L2 --, the unit-split
+ *     kernel of rnn_wide.hip below ~8192 sequences, the batch-block kernel of rnn_layer.h above); BATCH / UNITS /
+ *     CLUSTER force one family (UNITS needs hidden > 32; CLUSTER is an error where it cannot run).
  *   td_set_dw_gemm: weight-gradient GEMMs.  AUTO = rocBLAS where the shape has no column remap, the in-tree
  *     split-K MFMA kernel otherwise; KERNEL = the in-tree kernel for every shape. */
-enum { TD_LAYER_KERNEL_AUTO = 0, TD_LAYER_KERNEL_BATCH = 1, TD_LAYER_KERNEL_UNITS = 2 };
+enum { TD_LAYER_KERNEL_AUTO = 0, TD_LAYER_KERNEL_BATCH = 1, TD_LAYER_KERNEL_UNITS = 2, TD_LAYER_KERNEL_CLUSTER = 3 };
 enum { TD_DW_GEMM_AUTO = 0, TD_DW_GEMM_KERNEL = 1 };
 TD_API int td_set_layer_kernel(int32_t mode);
-/* Which family a (cfg, batch) launch takes under the current mode: TD_LAYER_KERNEL_BATCH or _UNITS (-1: bad cfg). */
-TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch);
+/* Which family a (cfg, batch, seq_len) launch takes under the current mode: TD_LAYER_KERNEL_BATCH, _UNITS or _CLUSTER
+ * (-1: bad cfg, or a forced family that cannot run this shape). */
+TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
 TD_API int td_set_dw_gemm(int32_t mode);
 
 /* Measurement aid, no counterpart in the reference: while enabled, every recurrent-layer kernel of the

@@ -47,9 +47,9 @@ def knob():
     L.td_set_layer_kernel(_lib.LAYER_KERNEL_AUTO)
 
 
-def _choice(den, B):
+def _choice(den, B, L=6):
     from timediff_amd import _lib
-    return _lib.lib().td_rnn_layer_kernel_choice(C.byref(den.cfg), B)
+    return _lib.lib().td_rnn_layer_kernel_choice(C.byref(den.cfg), B, L)
 
 
 def _check_forward_and_grads(den, sd, x, t, gy, rows, dev, tol_y=2e-2):
@@ -120,7 +120,8 @@ def test_auto_dispatch_above_switch(H, gru, dirs, B, dev):
     sd = random_state(H, Cc, layers, dirs, gru, seed=H + gru)
     den = den_kernels(sd, dev)
     assert _choice(den, B) == _lib.LAYER_KERNEL_BATCH, "this batch should run the batch-block kernel"
-    assert _choice(den, 64) == (_lib.LAYER_KERNEL_UNITS if H > 32 else _lib.LAYER_KERNEL_BATCH)
+    small = _lib.LAYER_KERNEL_CLUSTER if H > 192 else (_lib.LAYER_KERNEL_UNITS if H > 32 else _lib.LAYER_KERNEL_BATCH)
+    assert _choice(den, 64) == small
     x, t, rng = _inputs(B, Cc, L, n_num, seed=H)
     rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(0, B, 97), np.arange(B - 48, B)]))
     gy = np.zeros((B, Cc, L), np.float32)
@@ -180,3 +181,53 @@ def test_large_batch_chain_graph_equals_stepwise(dev):
     rows = np.unique(np.concatenate([np.arange(0, 33), np.arange(0, B, 211), np.arange(B - 40, B)]))
     y16 = orc.Denoiser(sd, bf16=True).forward(x_in.cpu().numpy()[rows], np.full(len(rows), T - 1))
     assert np.abs(mo[rows] - y16).max() < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# the cluster-persistent kernel (rnn_cluster.hip): small batches at hidden 193..256
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gru", [0, 1])
+@pytest.mark.parametrize("shape", ["bi_c14", "uni_c23"])
+@pytest.mark.parametrize("H,B,L", [(256, 37, 7), (250, 150, 5), (256, 32, 33)])
+def test_cluster_family_forced(H, B, L, gru, shape, dev, knob):
+    """Every instantiation of td_rnn_cluster_kernel (layer-0 input k-steps 1 / 2, one / two directions, LSTM / GRU,
+    inference / saving): 8 workgroups per batch block and direction exchange h_t through L2 every step.  Forward against
+    the bf16-emulating oracle, saving forward == inference forward bit for bit, and the existing BPTT on the values
+    this kernel saved against the fp32 oracle's gradients."""
+    from timediff_amd import _lib
+    knob(_lib.LAYER_KERNEL_CLUSTER)
+    dirs, Cc, n_num = (2, 14, 4) if shape == "bi_c14" else (1, 23, 7)
+    sd = random_state(H, Cc, 3, dirs, gru, seed=H + 10 * gru + dirs + L)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_CLUSTER
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=L)
+    gy = (rng.standard_normal((B, Cc, L)) / (B * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
+
+
+def test_cluster_dispatch_and_agreement(dev, knob):
+    """AUTO takes the cluster kernel where it can run (hidden 193..256, at most 512 sequences bidirectional, at least 4
+    steps) and nothing else; its results agree with the unit-split kernel's within the bf16 bound, run to run
+    bit-identically; forcing it on a shape it cannot run is an error, not a fallback."""
+    from timediff_amd import _lib
+    sd = random_state(256, 14, 3, 2, 0, seed=3)
+    den = den_kernels(sd, dev)
+    assert _choice(den, 100, 272) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 512, 272) == _lib.LAYER_KERNEL_CLUSTER
+    assert _choice(den, 513, 272) == _lib.LAYER_KERNEL_UNITS and _choice(den, 100, 3) == _lib.LAYER_KERNEL_UNITS
+    x, t, _ = _inputs(300, 14, 9, 4, seed=9)
+    out = {}
+    for mode in (_lib.LAYER_KERNEL_CLUSTER, _lib.LAYER_KERNEL_UNITS):
+        knob(mode)
+        a = den.forward(cu(x, dev), cu(t, dev)).cpu().numpy()
+        b = den.forward(cu(x, dev), cu(t, dev)).cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+        out[mode] = a
+    assert np.isfinite(out[_lib.LAYER_KERNEL_CLUSTER]).all()
+    assert np.abs(out[_lib.LAYER_KERNEL_CLUSTER] - out[_lib.LAYER_KERNEL_UNITS]).max() < BF16_EMUL_ATOL
+    knob(_lib.LAYER_KERNEL_CLUSTER)
+    assert _choice(den, 600, 9) == -1
+    with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
+        den.forward(cu(np.zeros((600, 14, 9), np.float32), dev), cu(np.zeros(600, np.int64), dev))
+    small = den_kernels(random_state(64, 14, 2, 2, 0, seed=1), dev)
+    with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
+        small.forward(cu(np.zeros((8, 14, 9), np.float32), dev), cu(np.zeros(8, np.int64), dev))

@@ -20,7 +20,7 @@ MISC_KEYS = ["time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_
              "fc.weight", "fc.bias"]
 
 
-LAYER_KERNEL_AUTO, LAYER_KERNEL_BATCH, LAYER_KERNEL_UNITS = 0, 1, 2     # td_set_layer_kernel
+LAYER_KERNEL_AUTO, LAYER_KERNEL_BATCH, LAYER_KERNEL_UNITS, LAYER_KERNEL_CLUSTER = 0, 1, 2, 3     # td_set_layer_kernel
 DW_GEMM_AUTO, DW_GEMM_KERNEL = 0, 1                                     # td_set_dw_gemm
 
 
@@ -84,7 +84,7 @@ _SIGS = {
     "td_clip_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, _I, _I, C.c_float, _P]),
     "td_set_layer_kernel": (C.c_int, [_I]),
-    "td_rnn_layer_kernel_choice": (C.c_int, [C.POINTER(RnnConfig), _I]),
+    "td_rnn_layer_kernel_choice": (C.c_int, [C.POINTER(RnnConfig), _I, _I]),
     "td_set_dw_gemm": (C.c_int, [_I]),
     "td_profile_enable": (C.c_int, [_I]),
     "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
@@ -109,8 +109,8 @@ def lib():
         _lib = handle
         # measurement switches of the tools (tools/perf_probe.py): applied once at load through the explicit knobs
         mode = os.environ.get("TIMEDIFF_LAYER_KERNEL", "")
-        if mode[:1] in ("b", "u"):
-            handle.td_set_layer_kernel(LAYER_KERNEL_BATCH if mode[0] == "b" else LAYER_KERNEL_UNITS)
+        if mode[:1] in ("b", "u", "c"):
+            handle.td_set_layer_kernel({"b": LAYER_KERNEL_BATCH, "u": LAYER_KERNEL_UNITS, "c": LAYER_KERNEL_CLUSTER}[mode[0]])
         if os.environ.get("TIMEDIFF_DW_GEMM", "")[:1] == "k":
             handle.td_set_dw_gemm(DW_GEMM_KERNEL)
     return _lib

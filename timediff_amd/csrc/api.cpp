@@ -25,7 +25,7 @@ int td_layer_kernel_mode(void) { return g_layer_kernel; }
 int td_dw_gemm_mode(void) { return g_dw_gemm; }
 
 extern "C" int td_set_layer_kernel(int32_t mode) {
-    if (mode != TD_LAYER_KERNEL_AUTO && mode != TD_LAYER_KERNEL_BATCH && mode != TD_LAYER_KERNEL_UNITS) {
+    if (mode != TD_LAYER_KERNEL_AUTO && mode != TD_LAYER_KERNEL_BATCH && mode != TD_LAYER_KERNEL_UNITS && mode != TD_LAYER_KERNEL_CLUSTER) {
         td_set_error("td_set_layer_kernel: unknown mode %d", mode);
         return TD_ERR_INVALID;
     }

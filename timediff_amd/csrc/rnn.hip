@@ -6,6 +6,12 @@
 #include <math.h>
 
 int td_layer_kernel_mode(void);   // api.cpp
+// rnn_cluster.hip
+size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);
+bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L);
+int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, const float *const *w, char *dst, hipStream_t stream);
+int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayerParams &lp, const char *wcluster, size_t dir_stride,
+                            bool layer0, unsigned long long *xch, hipStream_t stream);
 
 extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
     TdRnnGeom g;
@@ -14,8 +20,21 @@ extern "C" size_t td_rnn_packed_bytes(const td_rnn_config *cfg) {
 }
 
 // wide layers (rnn_wide.hip) keep the recurrent state of a step in a scratch region, one per direction
+// ... and the cluster kernel (rnn_cluster.hip) exchanges h_t between its workgroups through one (twice the size)
 static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
-    return g.nu >= 2 ? (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.nu * 1024 * sizeof(float) : 0;
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    const size_t wide = g.nu >= 2 ? (size_t)nbb * g.nu * 1024 * sizeof(float) : 0;
+    const size_t cl = g.nu == TD_CLUSTER_NU ? td_cluster_xch_dir_bytes(g, nbb) : 0;
+    return wide > cl ? wide : cl;
+}
+
+// The cluster-persistent kernel takes the small batches of the widths it is instantiated for: NU workgroups per batch
+// block and direction, all resident at once.  TD_LAYER_KERNEL_CLUSTER forces it (an error where it cannot run),
+// BATCH / UNITS exclude it.
+static bool td_use_cluster(const TdRnnGeom &g, int nbb, int L) {
+    const int force = td_layer_kernel_mode();
+    if (force == TD_LAYER_KERNEL_BATCH || force == TD_LAYER_KERNEL_UNITS) return false;
+    return td_cluster_supported(g, nbb, L);
 }
 
 // Which recurrent-layer kernel runs a layer.  rnn_layer.h (a wave = a batch block, all units) needs
@@ -37,10 +56,13 @@ static bool td_use_wide(const TdRnnGeom &g, int nbb) {
     return td_cdiv(nbb, TD_BLOCK_WAVES) * g.dirs <= 128;
 }
 
-extern "C" int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch) {
+extern "C" int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch, int32_t seq_len) {
     TdRnnGeom g;
-    if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0) return -1;
-    return td_use_wide(g, td_cdiv(batch, TD_WAVE_BATCH)) ? TD_LAYER_KERNEL_UNITS : TD_LAYER_KERNEL_BATCH;
+    if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0 || seq_len <= 0) return -1;
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    if (td_use_cluster(g, nbb, seq_len)) return TD_LAYER_KERNEL_CLUSTER;
+    if (td_layer_kernel_mode() == TD_LAYER_KERNEL_CLUSTER) return -1;
+    return td_use_wide(g, nbb) ? TD_LAYER_KERNEL_UNITS : TD_LAYER_KERNEL_BATCH;
 }
 
 // workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]
@@ -149,6 +171,10 @@ extern "C" int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const 
             if (blocks > 4096) blocks = 4096;
             hipLaunchKernelGGL(td_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
             TD_LAUNCH_CHECK();
+            if (g.nu == TD_CLUSTER_NU) {
+                rc = td_cluster_pack(cfg, g, l, w, (char *)packed + g.cl_off[l] + (size_t)d * g.cl_dir[l == 0 ? 0 : 1], (hipStream_t)stream);
+                if (rc != TD_OK) return rc;
+            }
         }
     return TD_OK;
 }
@@ -494,7 +520,16 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
         p.state = state;
         p.state_dir_stride = td_state_dir_bytes(g, batch) / sizeof(float);
         const int kxsel = l == 0 ? g.kx0 : g.dirs;
-        if (td_use_wide(g, nbb)) {
+        if (td_layer_kernel_mode() == TD_LAYER_KERNEL_CLUSTER && !td_use_cluster(g, nbb, L)) {
+            td_set_error("the cluster kernel was forced but cannot run hidden = %d, batch = %d, seq_len = %d", cfg->hidden, batch, L);
+            return TD_ERR_UNSUPPORTED;
+        }
+        if (td_use_cluster(g, nbb, L)) {
+            const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
+            rc = td_launch_layer_cluster(cfg->gru, saves ? 1 : 0, g, p, (const char *)packed + g.cl_off[l], g.cl_dir[l == 0 ? 0 : 1],
+                                         l == 0, (unsigned long long *)state, stream);
+            td_profile_end(slot, stream);
+        } else if (td_use_wide(g, nbb)) {
             const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
             rc = td_launch_layer_wide(cfg->gru, saves ? 1 : 0, g.nu, p, l == 0, g.kx0, stream);
             td_profile_end(slot, stream);

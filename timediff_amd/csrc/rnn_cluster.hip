@@ -1,0 +1,348 @@
+// Cluster-persistent recurrent layer (forward): the small-batch kernel of the denoiser (blocks.py:289, nn.LSTM / nn.GRU
+// with zero initial state), for the reference's own batch sizes (32 for training, 100 for sampling) up to a few hundred
+// sequences.
+//
+// rnn_layer.h gives 32 sequences to one wave and streams the layer's 1.5 MiB of weights through every CU once per
+// time step; rnn_wide.hip splits the units over the waves of ONE workgroup.  Either way a batch of 32 sequences keeps
+// two CUs of 256 busy and a time step costs the L2 -> CU transfer of the whole weight matrix (21 us at H = 256).  Here
+// a batch block of 32 sequences and one direction is worked by a CLUSTER of NU workgroups on NU CUs (NU = H / 32):
+//   * workgroup c owns the 32 hidden units [32c, 32c + 32): wave w the 8 units [32c + 8w, +8) with all their gates,
+//     as ONE 32-row MFMA tile whose rows are ordered (gate, unit), so that lane (sequence m, half hf) ends up with
+//     every gate of its 4 units in its 16 accumulator registers and the gate nonlinearities need no exchange;
+//   * the wave's slice of [W_hh | W_ih] (KH + KX fragments of 1 KiB = 192 registers at H = 256, bidirectional input)
+//     is loaded ONCE and stays in registers for the whole sequence: nothing is streamed per step but activations;
+//   * the input projection of step t + 1 (32 MFMAs, no dependence on the recurrence) runs while h_t is on its way;
+//   * per step the NU workgroups exchange h_t (16 KiB) through L2 as 8-byte {payload, tag} granules written and polled
+//     with relaxed agent-scope 64-bit atomics (each granule is self-validating: no flag, no fence; MI355X_MICROARCH.md,
+//     "Valid forms": 8-byte agent atomics on both sides).  The tag is (launch epoch, step), so stale data of an earlier
+//     step or launch never matches.  A workgroup may overwrite a parity buffer only after it has received every
+//     peer's h of the step in between, which each peer produced after its own reads of the older buffer.
+// Every workgroup of a launch must be resident at once (NU * dirs * batch blocks <= 256 CUs, one workgroup per CU by
+// its register use): the launcher checks this; every spin is bounded, and a timeout poisons the output with NaNs
+// (a hang would take the GPU with it, a wrong-but-finite result would go unnoticed).
+//
+// Activations in and out, and the values saved for the backward pass, use the layouts of the other kernel families
+// (rnn_layout.h, rnn_params.h): the cluster kernel is a drop-in per layer launch.
+#include "rnn_geom.h"
+#include "rnn_params.h"
+
+#define TDC_WAVES 4
+#define TDC_SPIN_LIMIT (1 << 22)
+
+// packed weights of one (layer, direction): [c (NU)][wave (4)] slices, each = 64 lanes x 16 fp32 bias (4 KiB) followed by
+// NFR fragments of 1 KiB (bf16): KH recurrent k-steps, then the input k-steps (layer 0: hi, lo per 16 channels)
+__host__ __device__ static inline size_t tdc_slice_bytes(int nfr) { return 4096 + (size_t)nfr * TD_FRAG_BYTES; }
+
+struct TdClusterPack {
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    char *dst;
+    int H, In, nu, kh, nfr, layer0, kx0, dirs_in, gru;
+};
+
+// gate slot -> torch row block and scale.  LSTM slots i, f, g, o; GRU slots r, z, n (input part), n (hidden part).
+__device__ __forceinline__ int tdc_row_block(int gru, int slot) { return gru ? (slot < 2 ? slot : 2) : slot; }
+__device__ __forceinline__ float tdc_scale(int gru, int slot) {
+    const bool tanh_gate = gru ? slot >= 2 : slot == 2;
+    return tanh_gate ? TD_GATE_SCALE_TANH : TD_GATE_SCALE_SIGMOID;
+}
+
+__global__ void td_cluster_pack_kernel(TdClusterPack p) {
+    const size_t slice = tdc_slice_bytes(p.nfr);
+    const size_t per_slice = 1024 + (size_t)p.nfr * 512;   // elements: 1024 fp32 bias + nfr * 512 bf16
+    const size_t total = (size_t)p.nu * TDC_WAVES * per_slice;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(idx / per_slice);
+        const size_t e = idx % per_slice;
+        const int c = sl / TDC_WAVES, w = sl % TDC_WAVES;
+        char *base = p.dst + (size_t)sl * slice;
+        if (e < 1024) {
+            // bias as the accumulator's initial value: lane (m, hf), register 4 slot + i <-> unit 32c + 8w + 4hf + i
+            const int lane = (int)(e / 16), reg = (int)(e % 16);
+            const int hf = lane >> 5, slot = reg >> 2, i = reg & 3;
+            const int unit = 32 * c + 8 * w + 4 * hf + i;
+            float b = 0.f;
+            if (unit < p.H) {
+                const int rb = tdc_row_block(p.gru, slot);
+                if (!p.gru || slot < 2) b = p.b_ih[rb * p.H + unit] + p.b_hh[rb * p.H + unit];
+                else if (slot == 2) b = p.b_ih[2 * p.H + unit];
+                else b = p.b_hh[2 * p.H + unit];
+            }
+            ((float *)base)[e] = b * tdc_scale(p.gru, slot);
+            continue;
+        }
+        const size_t fe = e - 1024;
+        const int f = (int)(fe / 512), lane = (int)((fe % 512) / 8), j = (int)(fe % 8);
+        const int rho = lane & 31, hf = lane >> 5;          // A operand: lane holds row rho, k = 8 hf + j of the k-step
+        const int slot = rho >> 3, unit = 32 * c + 8 * w + (rho & 7);
+        const int rb = tdc_row_block(p.gru, slot);
+        const float s = tdc_scale(p.gru, slot);
+        float v = 0.f;
+        bool lo = false;
+        if (unit < p.H) {
+            if (f < p.kh) {            // recurrent k-step f: hidden unit order of the activation fragments
+                const int kk = 16 * f + 8 * (j >> 2) + 4 * hf + (j & 3);
+                if (kk < p.H && !(p.gru && slot == 2)) v = p.w_hh[(size_t)(rb * p.H + unit) * p.H + kk];
+            } else if (p.layer0) {     // first layer: natural channel order, bf16 hi + lo parts
+                const int x = f - p.kh, kx = x >> 1;
+                lo = x & 1;
+                const int ch = 16 * kx + 8 * hf + j;
+                if (ch < p.In && !(p.gru && slot == 3)) v = p.w_ih[(size_t)(rb * p.H + unit) * p.In + ch];
+            } else {
+                const int x = f - p.kh, din = x / p.kh, ks = x % p.kh;
+                const int kk = 16 * ks + 8 * (j >> 2) + 4 * hf + (j & 3);
+                if (kk < p.H && !(p.gru && slot == 3)) v = p.w_ih[(size_t)(rb * p.H + unit) * p.In + din * p.H + kk];
+            }
+        }
+        v *= s;
+        if (lo) v = v - (float)(__bf16)v;
+        ((__bf16 *)(base + 4096))[fe] = (__bf16)v;
+    }
+}
+
+struct TdClusterParams {
+    const char *wpacked;      // this layer, direction 0
+    size_t dir_stride;
+    const char *xin;          // input fragments  [l][bblk][in_frags][64][8] bf16
+    char *out;                // output fragments [l][bblk][out_frags][64][8] bf16
+    float *save;              // training: [dir][l][bblk][u][5][64][16] fp32 (rnn_params.h)
+    size_t save_dir_stride;
+    unsigned long long *xch;  // [dir][bblk][parity][NU * 4 waves * 64 lanes * 2] granules
+    int in_frags, out_frags, L, nbb, dirs;
+    unsigned epoch;
+};
+
+__device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsigned tag) {
+    return ((unsigned long long)tag << 32) | payload;
+}
+
+template <int NU, int XF, bool L0, bool GRU, bool SAVE>
+__global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams p) {
+    constexpr int KH = 2 * NU;                       // recurrent k-steps
+    constexpr int NFR = KH + XF;                     // weight fragments per wave (layer 0: XF = 2 kx0 hi/lo fragments)
+    constexpr int XSTAGE = L0 ? 0 : XF;              // input fragments staged in LDS per step
+    constexpr int NPOLL = NU * TDC_WAVES * 64 * 2 / 256;   // granules per thread and step
+    constexpr int XLOAD = XSTAGE / TDC_WAVES;        // input fragments each wave brings in per step
+    static_assert(L0 || XF % TDC_WAVES == 0, "input fragments must split over the waves");
+    __shared__ __attribute__((aligned(16))) char lds[KH * TD_FRAG_BYTES + 2 * (XSTAGE ? XSTAGE : 1) * TD_FRAG_BYTES];
+    char *hbuf = lds, *xbuf = lds + KH * TD_FRAG_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x % NU, grp = blockIdx.x / NU;
+    const int dir = grp % p.dirs, bb = grp / p.dirs;
+
+    // ---- weights: once, into registers --------------------------------------------------------------------
+    const char *wsl = p.wpacked + (size_t)dir * p.dir_stride + (size_t)(c * TDC_WAVES + w) * tdc_slice_bytes(NFR);
+    f32x16 bias;
+    {
+        const f32x4 *bp = (const f32x4 *)wsl + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = bp[q];
+            bias[4 * q] = v[0]; bias[4 * q + 1] = v[1]; bias[4 * q + 2] = v[2]; bias[4 * q + 3] = v[3];
+        }
+    }
+    bf16x8 W[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) W[f] = *((const bf16x8 *)(wsl + 4096 + (size_t)f * TD_FRAG_BYTES) + lane);
+
+    unsigned long long *xch = p.xch + ((size_t)(dir * p.nbb + bb) * 2) * (NU * TDC_WAVES * 128);
+    const unsigned tag0 = p.epoch << 12;
+    float state[4] = {0.f, 0.f, 0.f, 0.f};       // LSTM: c; GRU: h (fp32), units 32c + 8w + 4hf + i
+    bool dead = false;                            // a spin timed out: stop waiting, poison the output
+
+    auto xrow = [&](int l) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
+    // stage the input fragments of position l into xbuf[par]: wave w brings fragments w, w + 4, ...
+    bf16x8 xpre[XLOAD ? XLOAD : 1];
+    auto x_issue = [&](int l) {
+        if constexpr (!L0) {
+            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
+#pragma unroll
+            for (int i = 0; i < XLOAD; ++i) xpre[i] = xp[(size_t)(w + TDC_WAVES * i) * 64];
+        }
+    };
+    auto x_commit = [&](int par) {
+        if constexpr (!L0) {
+            bf16x8 *xd = (bf16x8 *)(xbuf + (size_t)par * XSTAGE * TD_FRAG_BYTES) + lane;
+#pragma unroll
+            for (int i = 0; i < XLOAD; ++i) xd[(size_t)(w + TDC_WAVES * i) * 64] = xpre[i];
+        }
+    };
+    x_issue(dir ? p.L - 1 : 0);
+    x_commit(0);
+
+    for (int s = 0; s < p.L; ++s) {
+        const int l = dir ? p.L - 1 - s : s;
+        __syncthreads();     // xbuf[s & 1] is complete; every wave is done with hbuf and with xbuf[(s + 1) & 1]
+        // next step's inputs: in flight during this step, written to LDS at its end
+        if (s + 1 < p.L) x_issue(dir ? l - 1 : l + 1);
+        // (a) h_{s-1} from every workgroup of the cluster: issue the granule loads now, look at them after the input MFMAs
+        const unsigned long long *src = xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128);   // parity of step s - 1
+        unsigned long long gr[NPOLL];
+        if (s > 0) {
+#pragma unroll
+            for (int n = 0; n < NPOLL; ++n)
+                gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (b) input projection of this step
+        f32x16 acc = bias;
+        if constexpr (L0) {
+            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
+#pragma unroll
+            for (int kx = 0; kx < XF / 2; ++kx) {
+                const bf16x8 xh = xp[(size_t)(2 * kx) * 64], xl = xp[(size_t)(2 * kx + 1) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx + 1], xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xh, acc, 0, 0, 0);
+            }
+        } else {
+            const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)(s & 1) * XSTAGE * TD_FRAG_BYTES) + lane;
+#pragma unroll
+            for (int f = 0; f < XF; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + f], xs[(size_t)f * 64], acc, 0, 0, 0);
+        }
+        // (c) complete the hand-off: every granule must carry the tag of step s - 1
+        if (s > 0) {
+            const unsigned want = tag0 | (unsigned)s;      // h_{s-1} was published with tag (epoch, s)
+            int spins = 0;
+            while (!dead) {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
+                if (ok) break;
+                if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int n = 0; n < NPOLL; ++n)
+                    if ((unsigned)(gr[n] >> 32) != want)
+                        gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // granule g = ((c' * 4 + w') * 64 + lane') * 2 + e  ->  fragment 2c' + (w' >> 1), lane', bytes 8 (w' & 1) + 4 e
+#pragma unroll
+            for (int n = 0; n < NPOLL; ++n) {
+                const int g = tid + 256 * n;
+                const int e = g & 1, ln = (g >> 1) & 63, wp = (g >> 7) & 3, cp = g >> 9;
+                *(unsigned *)(hbuf + (size_t)(2 * cp + (wp >> 1)) * TD_FRAG_BYTES + ln * 16 + 8 * (wp & 1) + 4 * e) = (unsigned)gr[n];
+            }
+        }
+        __syncthreads();     // h_{s-1} is in LDS as B fragments
+        // (d) recurrent part
+        if (s > 0) {
+            const bf16x8 *hs = (const bf16x8 *)hbuf + lane;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ks], hs[(size_t)ks * 64], acc, 0, 0, 0);
+        }
+        // (e) gates: register 4 slot + i = slot's pre-activation of unit i, already scaled for exp2
+        float hval[4];
+        f32x4 sv[5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            constexpr float P2L2E = TD_GATE_SCALE_TANH;
+            if constexpr (!GRU) {
+                const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[i]));
+                const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 + i]));
+                const float gg = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[8 + i]) + 1.0f), 1.0f);
+                const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[12 + i]));
+                const float cv = __builtin_fmaf(fg, state[i], ig * gg);
+                state[i] = cv;
+                const float th = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(P2L2E * cv) + 1.0f), 1.0f);
+                hval[i] = og * th;
+                if constexpr (SAVE) { sv[0][i] = ig; sv[1][i] = fg; sv[2][i] = gg; sv[3][i] = og; sv[4][i] = cv; }
+            } else {
+                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[i]));
+                const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 + i]));
+                const float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[12 + i], acc[8 + i]));
+                const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t2 + 1.0f), 1.0f);
+                const float h = __builtin_fmaf(zg, state[i], (1.0f - zg) * ng);
+                state[i] = h;
+                hval[i] = h;
+                if constexpr (SAVE) { sv[0][i] = rg; sv[1][i] = zg; sv[2][i] = ng; sv[3][i] = acc[12 + i] * (1.0f / P2L2E); sv[4][i] = h; }
+            }
+        }
+        if (dead) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hval[i] = __builtin_nanf("");
+        }
+        typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+        bf16x4 hb = {(__bf16)hval[0], (__bf16)hval[1], (__bf16)hval[2], (__bf16)hval[3]};
+        const unsigned long long hbits = *(const unsigned long long *)&hb;
+        // publish: two granules per lane, tag = (epoch, s + 1)
+        {
+            unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + ((size_t)(c * TDC_WAVES + w) * 64 + lane) * 2;
+            const unsigned tag = tag0 | (unsigned)(s + 1);
+            if (s + 1 < p.L) {
+                __hip_atomic_store(dst, tdc_granule((unsigned)hbits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, tdc_granule((unsigned)(hbits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // the layer's output (next layer / head / weight gradients read it after this launch)
+        *(unsigned long long *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + 2 * c + (w >> 1)) * TD_FRAG_BYTES +
+                                lane * 16 + 8 * (w & 1)) = hbits;
+        if constexpr (SAVE) {
+            float *svp = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bb) * NU + c) * 5) * 1024 + lane * 16 + 4 * w;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) *(f32x4 *)(svp + q * 1024) = sv[q];
+        }
+        if (s + 1 < p.L) x_commit((s + 1) & 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static unsigned g_cluster_epoch = 0;
+
+size_t td_cluster_packed_bytes(const TdRnnGeom &g, int layer0, int kx0) {
+    const int nfr = g.kh + (layer0 ? 2 * kx0 : g.dirs * g.kh);
+    return (size_t)g.nu * TDC_WAVES * tdc_slice_bytes(nfr);
+}
+
+// exchange scratch per direction: batch blocks x 2 parities x NU x 4 waves x 128 granules of 8 B
+size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb) { return (size_t)nbb * 2 * g.nu * TDC_WAVES * 128 * 8; }
+
+bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
+    // one workgroup per CU, all of them resident at once; tags carry 12 bits of step index; a parity buffer must have been
+    // rewritten by this launch before a step index of the previous launch can recur (L >= 4)
+    return g.nu == 8 && (size_t)g.nu * g.dirs * nbb <= 256 && L >= 4 && L < 4096;
+}
+
+int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, const float *const *w, char *dst, hipStream_t stream) {
+    TdClusterPack p;
+    p.w_ih = w[0]; p.w_hh = w[1]; p.b_ih = w[2]; p.b_hh = w[3];
+    p.dst = dst; p.H = cfg->hidden; p.In = layer == 0 ? cfg->c_in : cfg->dirs * cfg->hidden;
+    p.nu = g.nu; p.kh = g.kh; p.layer0 = layer == 0; p.kx0 = g.kx0; p.dirs_in = g.dirs; p.gru = cfg->gru;
+    p.nfr = g.kh + (layer == 0 ? 2 * g.kx0 : g.dirs * g.kh);
+    hipLaunchKernelGGL(td_cluster_pack_kernel, dim3(1024), dim3(256), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+template <int NU, int XF, bool L0>
+static int tdc_launch2(int gru, int save, const TdClusterParams &p, int blocks, hipStream_t stream) {
+    if (!gru && !save) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, false, false>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (!gru) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, false, true>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (!save) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, true, false>), dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, true, true>), dim3(blocks), dim3(256), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+// One layer, both directions.  `wcluster`: this layer's cluster-packed weights (direction 0), `dir_stride` to direction 1.
+int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayerParams &lp, const char *wcluster, size_t dir_stride,
+                            bool layer0, unsigned long long *xch, hipStream_t stream) {
+    TdClusterParams p;
+    p.wpacked = wcluster; p.dir_stride = dir_stride;
+    p.xin = lp.xin; p.out = lp.out; p.save = lp.save; p.save_dir_stride = lp.save_dir_stride;
+    p.xch = xch; p.in_frags = lp.in_frags; p.out_frags = lp.out_frags; p.L = lp.L; p.nbb = lp.nbb; p.dirs = lp.dirs;
+    p.epoch = (++g_cluster_epoch) & 0xFFFFFu;
+    const int blocks = g.nu * lp.dirs * lp.nbb;
+    if (g.nu != 8) {
+        td_set_error("cluster kernel: hidden block count %d is not instantiated", g.nu);
+        return TD_ERR_UNSUPPORTED;
+    }
+    if (layer0) {
+        if (g.kx0 == 1) return tdc_launch2<8, 2, true>(gru, save, p, blocks, stream);
+        return tdc_launch2<8, 4, true>(gru, save, p, blocks, stream);
+    }
+    if (lp.dirs == 1) return tdc_launch2<8, 16, false>(gru, save, p, blocks, stream);
+    return tdc_launch2<8, 32, false>(gru, save, p, blocks, stream);
+}

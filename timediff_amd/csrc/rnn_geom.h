@@ -10,8 +10,12 @@ struct TdRnnGeom {
     int nu, hpad, kh, kx0, dirs, layers;
     TdLayerGeom g0, g1;  // layer 0 / layers above
     size_t layer_off[16];
+    // cluster-persistent kernel (rnn_cluster.hip; hidden sizes with nu == TD_CLUSTER_NU): its own register-ordered copy
+    // of the weights, appended to the packed cache.  cl_dir[0 / 1]: bytes per direction of layer 0 / of a layer above.
+    size_t cl_off[16], cl_dir[2];
     size_t packed_bytes;
 };
+#define TD_CLUSTER_NU 8
 
 static inline int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
     TD_REQUIRE(cfg != nullptr, "td_rnn_config is NULL");
@@ -38,6 +42,16 @@ static inline int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
     for (int l = 0; l < cfg->layers; ++l) {
         g->layer_off[l] = off;
         off += (l == 0 ? g->g0.dir_bytes : g->g1.dir_bytes) * cfg->dirs;
+    }
+    g->cl_dir[0] = g->cl_dir[1] = 0;
+    if (nu == TD_CLUSTER_NU) {
+        // per (unit slice c, wave): 4 KiB of bias registers + one 1 KiB fragment per k-step (rnn_cluster.hip)
+        g->cl_dir[0] = (size_t)nu * 4 * (4096 + (size_t)(g->kh + 2 * kx0) * 1024);
+        g->cl_dir[1] = (size_t)nu * 4 * (4096 + (size_t)(g->kh + cfg->dirs * g->kh) * 1024);
+    }
+    for (int l = 0; l < cfg->layers; ++l) {
+        g->cl_off[l] = off;
+        off += g->cl_dir[l == 0 ? 0 : 1] * cfg->dirs;
     }
     g->packed_bytes = off;
     return TD_OK;

@@ -16,6 +16,7 @@ int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, i
     return td_launch_layer_dispatch(gru, 1, nu, p, layer0, kxsel, stream);
 }
 
+size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);   // rnn_cluster.hip
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
                          char *const *acts, float *const *saves, float *state, hipStream_t stream);
 // gemm_lib.cpp (rocBLAS)
@@ -60,7 +61,11 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
             t.dapl[l][d] = take(4 * t.dapl_slab_elems * 2);
         }
     for (int d = 0; d < 2; ++d) t.dhrec[d] = take((size_t)t.nbb * g.kh * TD_FRAG_BYTES);
-    for (int d = 0; d < 2; ++d) t.dc[d] = take((size_t)t.nbb * g.nu * 1024 * sizeof(float));   // back to back (a multiple of 256 B each)
+    {   // back to back (a multiple of 256 B each); the forward pass uses the pair as the layer kernels' state / exchange scratch
+        size_t dcb = (size_t)t.nbb * g.nu * 1024 * sizeof(float);
+        if (g.nu == TD_CLUSTER_NU && td_cluster_xch_dir_bytes(g, t.nbb) > dcb) dcb = td_cluster_xch_dir_bytes(g, t.nbb);
+        for (int d = 0; d < 2; ++d) t.dc[d] = take(dcb);
+    }
     t.total = off;
     return t;
 }

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""One training probe of bench.py on its own (for rocprofv3 runs): python3 tools/train_probe.py --batch 32 --ga 2 --steps 20"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import EICU, train_probe  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--ga", type=int, default=2)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--hidden", type=int, default=256)
+ap.add_argument("--seq-len", type=int, default=272)
+a = ap.parse_args()
+torch.cuda.set_device(0)
+print(json.dumps(train_probe(torch.device("cuda", 0), EICU, a.seq_len, a.hidden, 3, 1000, a.batch, a.ga, a.steps, a.warmup)))
