@@ -205,6 +205,24 @@ def test_cluster_family_forced(H, B, L, gru, shape, dev, knob):
     _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
 
 
+@pytest.mark.parametrize("gru,dirs,B", [(0, 2, 600), (1, 2, 1300), (0, 1, 1100), (1, 1, 2100)])
+def test_cluster_several_blocks_per_cluster(gru, dirs, B, dev, knob):
+    """More batch blocks than clusters fit the chip (16 per direction bidirectional, 32 unidirectional): the pipelined
+    kernel, in which a cluster works its blocks one after the other within a step (some clusters one block fewer than
+    others), state in the L2-resident scratch.  Oracle on a subset of sequences, gradients with grad_y non-zero there."""
+    from timediff_amd import _lib
+    knob(_lib.LAYER_KERNEL_CLUSTER)
+    L, Cc, n_num = 6, 14, 4
+    sd = random_state(256, Cc, 3, dirs, gru, seed=B + gru)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_CLUSTER
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=B)
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(0, B, 37), np.arange(B - 48, B)]))
+    gy = np.zeros((B, Cc, L), np.float32)
+    gy[rows] = (rng.standard_normal((len(rows), Cc, L)) / (len(rows) * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, rows, dev)
+
+
 def test_cluster_dispatch_and_agreement(dev, knob):
     """AUTO takes the cluster kernel where it can run (hidden 193..256, at most 512 sequences bidirectional, at least 4
     steps) and nothing else; its results agree with the unit-split kernel's within the bf16 bound, run to run
@@ -212,8 +230,8 @@ def test_cluster_dispatch_and_agreement(dev, knob):
     from timediff_amd import _lib
     sd = random_state(256, 14, 3, 2, 0, seed=3)
     den = den_kernels(sd, dev)
-    assert _choice(den, 100, 272) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 512, 272) == _lib.LAYER_KERNEL_CLUSTER
-    assert _choice(den, 513, 272) == _lib.LAYER_KERNEL_UNITS and _choice(den, 100, 3) == _lib.LAYER_KERNEL_UNITS
+    assert _choice(den, 100, 272) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 1024, 272) == _lib.LAYER_KERNEL_CLUSTER
+    assert _choice(den, 1025, 272) == _lib.LAYER_KERNEL_UNITS and _choice(den, 100, 3) == _lib.LAYER_KERNEL_UNITS
     x, t, _ = _inputs(300, 14, 9, 4, seed=9)
     out = {}
     for mode in (_lib.LAYER_KERNEL_CLUSTER, _lib.LAYER_KERNEL_UNITS):
@@ -225,9 +243,9 @@ def test_cluster_dispatch_and_agreement(dev, knob):
     assert np.isfinite(out[_lib.LAYER_KERNEL_CLUSTER]).all()
     assert np.abs(out[_lib.LAYER_KERNEL_CLUSTER] - out[_lib.LAYER_KERNEL_UNITS]).max() < BF16_EMUL_ATOL
     knob(_lib.LAYER_KERNEL_CLUSTER)
-    assert _choice(den, 600, 9) == -1
+    assert _choice(den, 600, 9) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 600, 3) == -1
     with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
-        den.forward(cu(np.zeros((600, 14, 9), np.float32), dev), cu(np.zeros(600, np.int64), dev))
+        den.forward(cu(np.zeros((6, 14, 3), np.float32), dev), cu(np.zeros(6, np.int64), dev))
     small = den_kernels(random_state(64, 14, 2, 2, 0, seed=1), dev)
     with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
         small.forward(cu(np.zeros((8, 14, 9), np.float32), dev), cu(np.zeros(8, np.int64), dev))

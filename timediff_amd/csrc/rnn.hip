@@ -6,6 +6,9 @@
 #include <math.h>
 
 int td_layer_kernel_mode(void);   // api.cpp
+#ifndef TD_CLUSTER_AUTO_BLOCKS
+#define TD_CLUSTER_AUTO_BLOCKS 64   // x 32 sequences, both directions counted: 1024 bidirectional sequences (7 ms against 13 ms for the unit-split kernel there; equal at 2048)
+#endif
 // rnn_cluster.hip
 size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L);
@@ -31,10 +34,14 @@ static size_t td_state_dir_bytes(const TdRnnGeom &g, int batch) {
 // The cluster-persistent kernel takes the small batches of the widths it is instantiated for: NU workgroups per batch
 // block and direction, all resident at once.  TD_LAYER_KERNEL_CLUSTER forces it (an error where it cannot run),
 // BATCH / UNITS exclude it.
+// AUTO: up to this many batch blocks (measured switch point against the other two families)
+static int td_cluster_auto_max_blocks(const TdRnnGeom &g) { return TD_CLUSTER_AUTO_BLOCKS / g.dirs; }
 static bool td_use_cluster(const TdRnnGeom &g, int nbb, int L) {
     const int force = td_layer_kernel_mode();
     if (force == TD_LAYER_KERNEL_BATCH || force == TD_LAYER_KERNEL_UNITS) return false;
-    return td_cluster_supported(g, nbb, L);
+    if (!td_cluster_supported(g, nbb, L)) return false;
+    if (force == TD_LAYER_KERNEL_CLUSTER) return true;
+    return nbb <= td_cluster_auto_max_blocks(g);
 }
 
 // Which recurrent-layer kernel runs a layer.  rnn_layer.h (a wave = a batch block, all units) needs

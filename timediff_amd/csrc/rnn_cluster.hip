@@ -107,12 +107,98 @@ struct TdClusterParams {
     float *save;              // training: [dir][l][bblk][u][5][64][16] fp32 (rnn_params.h)
     size_t save_dir_stride;
     unsigned long long *xch;  // [dir][bblk][parity][NU * 4 waves * 64 lanes * 2] granules
+    float *cstate;            // [dir][bblk][c][wave][64 lanes][4] fp32: recurrent state of clusters that work several batch blocks
     int in_frags, out_frags, L, nbb, dirs;
+    int ngroups;              // clusters per direction; cluster gi works the batch blocks gi, gi + ngroups, ...
     unsigned epoch;
 };
 
 __device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsigned tag) {
     return ((unsigned long long)tag << 32) | payload;
+}
+
+// acc += sum_f W[w0 + f] x (B fragment f of `src`), f < NF: the B fragments come from LDS through a register ring RD deep,
+// each read issued RD MFMAs ahead of its use.  Left to the compiler the reads share one register quad and every MFMA waits
+// for its own ds_read (150 cycles per MFMA instead of 32); the scheduling barriers pin the interleaving.
+#define TDC_RING 8
+template <int NF, int W0, int NW>
+__device__ __forceinline__ void tdc_mfma_stream(f32x16 &acc, const bf16x8 (&W)[NW], const bf16x8 *src) {
+    constexpr int RD = NF < TDC_RING ? NF : TDC_RING;
+    bf16x8 R[RD];
+#pragma unroll
+    for (int i = 0; i < RD; ++i) R[i] = src[(size_t)i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[W0 + f], R[f % RD], acc, 0, 0, 0);
+        if (f + RD < NF) R[f % RD] = src[(size_t)(f + RD) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Gate nonlinearities of one (step, batch block) for this lane's 4 units, and everything that leaves the wave:
+// the recurrent state (to the scratch when the cluster works several blocks), h_t as tagged granules for the cluster,
+// h_t as activation fragment for the next layer, the saved gate values for the backward pass.
+template <int NU, bool GRU, bool SAVE>
+__device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const f32x16 &acc, f32x4 &state, bool dead, float *cptr,
+                                                unsigned long long *xch, unsigned tag0, int s, int l, int bb, int dir, int c, int w,
+                                                int lane) {
+    constexpr int KH = 2 * NU;
+    // register 4 slot + i = slot's pre-activation of unit i, already scaled for exp2
+    float hval[4];
+    f32x4 sv[5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        constexpr float P2L2E = TD_GATE_SCALE_TANH;
+        if constexpr (!GRU) {
+            const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[i]));
+            const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 + i]));
+            const float gg = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[8 + i]) + 1.0f), 1.0f);
+            const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[12 + i]));
+            const float cv = __builtin_fmaf(fg, state[i], ig * gg);
+            state[i] = cv;
+            const float th = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(P2L2E * cv) + 1.0f), 1.0f);
+            hval[i] = og * th;
+            if constexpr (SAVE) { sv[0][i] = ig; sv[1][i] = fg; sv[2][i] = gg; sv[3][i] = og; sv[4][i] = cv; }
+        } else {
+            const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[i]));
+            const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 + i]));
+            const float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[12 + i], acc[8 + i]));
+            const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t2 + 1.0f), 1.0f);
+            const float h = __builtin_fmaf(zg, state[i], (1.0f - zg) * ng);
+            state[i] = h;
+            hval[i] = h;
+            if constexpr (SAVE) { sv[0][i] = rg; sv[1][i] = zg; sv[2][i] = ng; sv[3][i] = acc[12 + i] * (1.0f / P2L2E); sv[4][i] = h; }
+        }
+    }
+    if (cptr) *(f32x4 *)cptr = state;
+    if (dead) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hval[i] = __builtin_nanf("");
+    }
+    typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+    bf16x4 hb = {(__bf16)hval[0], (__bf16)hval[1], (__bf16)hval[2], (__bf16)hval[3]};
+    const unsigned long long hbits = *(const unsigned long long *)&hb;
+    // publish: two granules per lane, tag = (epoch, s + 1)
+    if (s + 1 < p.L) {
+        unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + ((size_t)(c * TDC_WAVES + w) * 64 + lane) * 2;
+        const unsigned tag = tag0 | (unsigned)(s + 1);
+#ifndef TDC_DBG_PLAINSTORE
+        __hip_atomic_store(dst, tdc_granule((unsigned)hbits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, tdc_granule((unsigned)(hbits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        dst[0] = tdc_granule((unsigned)hbits, tag);
+        dst[1] = tdc_granule((unsigned)(hbits >> 32), tag);
+#endif
+    }
+    // the layer's output (next layer / head / weight gradients read it after this launch)
+    *(unsigned long long *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + 2 * c + (w >> 1)) * TD_FRAG_BYTES + lane * 16 +
+                            8 * (w & 1)) = hbits;
+    if constexpr (SAVE) {
+        float *svp = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bb) * NU + c) * 5) * 1024 + lane * 16 + 4 * w;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) *(f32x4 *)(svp + q * 1024) = sv[q];
+    }
 }
 
 template <int NU, int XF, bool L0, bool GRU, bool SAVE>
@@ -129,7 +215,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = blockIdx.x % NU, grp = blockIdx.x / NU;
-    const int dir = grp % p.dirs, bb = grp / p.dirs;
+    const int dir = grp % p.dirs, gi = grp / p.dirs;
+    const int nblk = (p.nbb - gi + p.ngroups - 1) / p.ngroups;   // batch blocks of this cluster (>= 1)
 
     // ---- weights: once, into registers --------------------------------------------------------------------
     const char *wsl = p.wpacked + (size_t)dir * p.dir_stride + (size_t)(c * TDC_WAVES + w) * tdc_slice_bytes(NFR);
@@ -146,17 +233,18 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
 #pragma unroll
     for (int f = 0; f < NFR; ++f) W[f] = *((const bf16x8 *)(wsl + 4096 + (size_t)f * TD_FRAG_BYTES) + lane);
 
-    unsigned long long *xch = p.xch + ((size_t)(dir * p.nbb + bb) * 2) * (NU * TDC_WAVES * 128);
     const unsigned tag0 = p.epoch << 12;
-    float state[4] = {0.f, 0.f, 0.f, 0.f};       // LSTM: c; GRU: h (fp32), units 32c + 8w + 4hf + i
+    // LSTM: c; GRU: h (fp32), units 32c + 8w + 4hf + i.  In registers when the cluster works ONE batch block, in the
+    // (L2-resident) state scratch between a block's steps otherwise.
+    f32x4 state = {0.f, 0.f, 0.f, 0.f};
     bool dead = false;                            // a spin timed out: stop waiting, poison the output
 
-    auto xrow = [&](int l) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
-    // stage the input fragments of position l into xbuf[par]: wave w brings fragments w, w + 4, ...
+    auto xrow = [&](int l, int bb) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
+    // stage the input fragments of (position l, block bb) into xbuf[par]: wave w brings fragments w, w + 4, ...
     bf16x8 xpre[XLOAD ? XLOAD : 1];
-    auto x_issue = [&](int l) {
+    auto x_issue = [&](int l, int bb) {
         if constexpr (!L0) {
-            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
+            const bf16x8 *xp = (const bf16x8 *)xrow(l, bb) + lane;
 #pragma unroll
             for (int i = 0; i < XLOAD; ++i) xpre[i] = xp[(size_t)(w + TDC_WAVES * i) * 64];
         }
@@ -168,121 +256,212 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
             for (int i = 0; i < XLOAD; ++i) xd[(size_t)(w + TDC_WAVES * i) * 64] = xpre[i];
         }
     };
-    x_issue(dir ? p.L - 1 : 0);
+    x_issue(dir ? p.L - 1 : 0, gi);
     x_commit(0);
 
+    int it = 0;       // iteration = (step s, block j): LDS staging alternates with its parity
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
-        __syncthreads();     // xbuf[s & 1] is complete; every wave is done with hbuf and with xbuf[(s + 1) & 1]
-        // next step's inputs: in flight during this step, written to LDS at its end
-        if (s + 1 < p.L) x_issue(dir ? l - 1 : l + 1);
-        // (a) h_{s-1} from every workgroup of the cluster: issue the granule loads now, look at them after the input MFMAs
-        const unsigned long long *src = xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128);   // parity of step s - 1
-        unsigned long long gr[NPOLL];
-        if (s > 0) {
-#pragma unroll
-            for (int n = 0; n < NPOLL; ++n)
-                gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // (b) input projection of this step
-        f32x16 acc = bias;
-        if constexpr (L0) {
-            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
-#pragma unroll
-            for (int kx = 0; kx < XF / 2; ++kx) {
-                const bf16x8 xh = xp[(size_t)(2 * kx) * 64], xl = xp[(size_t)(2 * kx + 1) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx + 1], xh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xh, acc, 0, 0, 0);
+        for (int j = 0; j < nblk; ++j, ++it) {
+            const int bb = gi + j * p.ngroups;
+            __syncthreads();     // xbuf[it & 1] is complete; every wave is done with hbuf and with xbuf[(it + 1) & 1]
+            // next iteration's inputs: in flight during this one, written to LDS at its end
+            const bool more = j + 1 < nblk || s + 1 < p.L;
+            if (more) {
+                if (j + 1 < nblk) x_issue(l, bb + p.ngroups);
+                else x_issue(dir ? l - 1 : l + 1, gi);
             }
-        } else {
-            const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)(s & 1) * XSTAGE * TD_FRAG_BYTES) + lane;
-#pragma unroll
-            for (int f = 0; f < XF; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + f], xs[(size_t)f * 64], acc, 0, 0, 0);
-        }
-        // (c) complete the hand-off: every granule must carry the tag of step s - 1
-        if (s > 0) {
-            const unsigned want = tag0 | (unsigned)s;      // h_{s-1} was published with tag (epoch, s)
-            int spins = 0;
-            while (!dead) {
-                bool ok = true;
-#pragma unroll
-                for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
-                if (ok) break;
-                if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+            unsigned long long *xch = p.xch + ((size_t)(dir * p.nbb + bb) * 2) * (NU * TDC_WAVES * 128);
+            float *cptr = p.cstate + ((((size_t)(dir * p.nbb + bb) * NU + c) * TDC_WAVES + w) * 64 + lane) * 4;
+            if (nblk > 1) state = s > 0 ? *(const f32x4 *)cptr : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (a) h_{s-1} of this block from every workgroup of the cluster: issue the granule loads now, look at them after
+            //     the input MFMAs
+            const unsigned long long *src = xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128);   // parity of step s - 1
+            unsigned long long gr[NPOLL];
+            if (s > 0) {
 #pragma unroll
                 for (int n = 0; n < NPOLL; ++n)
-                    if ((unsigned)(gr[n] >> 32) != want)
-                        gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // granule g = ((c' * 4 + w') * 64 + lane') * 2 + e  ->  fragment 2c' + (w' >> 1), lane', bytes 8 (w' & 1) + 4 e
+            // (b) input projection of this step
+            f32x16 acc = bias;
+            if constexpr (L0) {
+                const bf16x8 *xp = (const bf16x8 *)xrow(l, bb) + lane;
 #pragma unroll
-            for (int n = 0; n < NPOLL; ++n) {
-                const int g = tid + 256 * n;
-                const int e = g & 1, ln = (g >> 1) & 63, wp = (g >> 7) & 3, cp = g >> 9;
-                *(unsigned *)(hbuf + (size_t)(2 * cp + (wp >> 1)) * TD_FRAG_BYTES + ln * 16 + 8 * (wp & 1) + 4 * e) = (unsigned)gr[n];
-            }
-        }
-        __syncthreads();     // h_{s-1} is in LDS as B fragments
-        // (d) recurrent part
-        if (s > 0) {
-            const bf16x8 *hs = (const bf16x8 *)hbuf + lane;
-#pragma unroll
-            for (int ks = 0; ks < KH; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ks], hs[(size_t)ks * 64], acc, 0, 0, 0);
-        }
-        // (e) gates: register 4 slot + i = slot's pre-activation of unit i, already scaled for exp2
-        float hval[4];
-        f32x4 sv[5];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            constexpr float P2L2E = TD_GATE_SCALE_TANH;
-            if constexpr (!GRU) {
-                const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[i]));
-                const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 + i]));
-                const float gg = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[8 + i]) + 1.0f), 1.0f);
-                const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[12 + i]));
-                const float cv = __builtin_fmaf(fg, state[i], ig * gg);
-                state[i] = cv;
-                const float th = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(P2L2E * cv) + 1.0f), 1.0f);
-                hval[i] = og * th;
-                if constexpr (SAVE) { sv[0][i] = ig; sv[1][i] = fg; sv[2][i] = gg; sv[3][i] = og; sv[4][i] = cv; }
+                for (int kx = 0; kx < XF / 2; ++kx) {
+                    const bf16x8 xh = xp[(size_t)(2 * kx) * 64], xl = xp[(size_t)(2 * kx + 1) * 64];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx + 1], xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xh, acc, 0, 0, 0);
+                }
             } else {
-                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[i]));
-                const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 + i]));
-                const float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[12 + i], acc[8 + i]));
-                const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t2 + 1.0f), 1.0f);
-                const float h = __builtin_fmaf(zg, state[i], (1.0f - zg) * ng);
-                state[i] = h;
-                hval[i] = h;
-                if constexpr (SAVE) { sv[0][i] = rg; sv[1][i] = zg; sv[2][i] = ng; sv[3][i] = acc[12 + i] * (1.0f / P2L2E); sv[4][i] = h; }
+                const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)(it & 1) * XSTAGE * TD_FRAG_BYTES) + lane;
+                tdc_mfma_stream<XF, KH, NFR>(acc, W, xs);
             }
-        }
-        if (dead) {
+            // (c) complete the hand-off: every granule must carry the tag of step s - 1
+            if (s > 0) {
+                const unsigned want = tag0 | (unsigned)s;      // h_{s-1} was published with tag (epoch, s)
+                int spins = 0;
+                while (!dead) {
+                    bool ok = true;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hval[i] = __builtin_nanf("");
-        }
-        typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
-        bf16x4 hb = {(__bf16)hval[0], (__bf16)hval[1], (__bf16)hval[2], (__bf16)hval[3]};
-        const unsigned long long hbits = *(const unsigned long long *)&hb;
-        // publish: two granules per lane, tag = (epoch, s + 1)
-        {
-            unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + ((size_t)(c * TDC_WAVES + w) * 64 + lane) * 2;
-            const unsigned tag = tag0 | (unsigned)(s + 1);
-            if (s + 1 < p.L) {
-                __hip_atomic_store(dst, tdc_granule((unsigned)hbits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, tdc_granule((unsigned)(hbits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
+                    if (ok) break;
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int n = 0; n < NPOLL; ++n)
+                        if ((unsigned)(gr[n] >> 32) != want)
+                            gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // granule g = ((c' * 4 + w') * 64 + lane') * 2 + e  ->  fragment 2c' + (w' >> 1), lane', bytes 8 (w' & 1) + 4 e
+#pragma unroll
+                for (int n = 0; n < NPOLL; ++n) {
+                    const int g = tid + 256 * n;
+                    const int e = g & 1, ln = (g >> 1) & 63, wp = (g >> 7) & 3, cp = g >> 9;
+                    *(unsigned *)(hbuf + (size_t)(2 * cp + (wp >> 1)) * TD_FRAG_BYTES + ln * 16 + 8 * (wp & 1) + 4 * e) = (unsigned)gr[n];
+                }
             }
+            __syncthreads();     // h_{s-1} is in LDS as B fragments
+            // (d) recurrent part
+            if (s > 0) {
+                const bf16x8 *hs = (const bf16x8 *)hbuf + lane;
+                tdc_mfma_stream<KH, 0, NFR>(acc, W, hs);
+            }
+            tdc_finish_step<NU, GRU, SAVE>(p, acc, state, dead, nblk > 1 && s + 1 < p.L ? cptr : nullptr, xch, tag0, s, l, bb, dir, c, w, lane);
+            if (more) x_commit((it + 1) & 1);
         }
-        // the layer's output (next layer / head / weight gradients read it after this launch)
-        *(unsigned long long *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + 2 * c + (w >> 1)) * TD_FRAG_BYTES +
-                                lane * 16 + 8 * (w & 1)) = hbits;
-        if constexpr (SAVE) {
-            float *svp = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bb) * NU + c) * 5) * 1024 + lane * 16 + 4 * w;
+    }
+}
+
+// The same cluster, working SEVERAL batch blocks per step (batches beyond one block per cluster): block j's h_{s-1} was
+// published a whole round of blocks ago, so everything an iteration needs from memory (granules, input fragments,
+// recurrent state) is fetched one iteration ahead, under the previous block's 48 MFMAs, and one barrier per iteration
+// orders the double-buffered LDS staging.
+template <int NU, int XF, bool L0, bool GRU, bool SAVE>
+__global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterParams p) {
+    constexpr int KH = 2 * NU;
+    constexpr int NFR = KH + XF;
+    constexpr int XSTAGE = L0 ? XF : XF;             // input fragments staged in LDS per iteration (layer 0: its hi / lo pairs)
+    constexpr int NPOLL = NU * TDC_WAVES * 64 * 2 / 256;
+    constexpr int XLOAD = (XSTAGE + TDC_WAVES - 1) / TDC_WAVES;
+    __shared__ __attribute__((aligned(16))) char lds[2 * KH * TD_FRAG_BYTES + 2 * XSTAGE * TD_FRAG_BYTES];
+    char *hbuf = lds, *xbuf = lds + 2 * KH * TD_FRAG_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x % NU, grp = blockIdx.x / NU;
+    const int dir = grp % p.dirs, gi = grp / p.dirs;
+    const int nblk = (p.nbb - gi + p.ngroups - 1) / p.ngroups;
+
+    const char *wsl = p.wpacked + (size_t)dir * p.dir_stride + (size_t)(c * TDC_WAVES + w) * tdc_slice_bytes(NFR);
+    f32x16 bias;
+    {
+        const f32x4 *bp = (const f32x4 *)wsl + lane * 4;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) *(f32x4 *)(svp + q * 1024) = sv[q];
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = bp[q];
+            bias[4 * q] = v[0]; bias[4 * q + 1] = v[1]; bias[4 * q + 2] = v[2]; bias[4 * q + 3] = v[3];
         }
-        if (s + 1 < p.L) x_commit((s + 1) & 1);
+    }
+    bf16x8 W[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) W[f] = *((const bf16x8 *)(wsl + 4096 + (size_t)f * TD_FRAG_BYTES) + lane);
+
+    const unsigned tag0 = p.epoch << 12;
+    bool dead = false;
+    auto xrow = [&](int l, int bb) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
+    auto xchp = [&](int bb) { return p.xch + ((size_t)(dir * p.nbb + bb) * 2) * (NU * TDC_WAVES * 128); };
+    auto cstp = [&](int bb) { return p.cstate + ((((size_t)(dir * p.nbb + bb) * NU + c) * TDC_WAVES + w) * 64 + lane) * 4; };
+
+    // what the NEXT iteration needs, fetched during the current one
+    bf16x8 xpre[XLOAD];
+    unsigned long long gr[NPOLL];
+    f32x4 st_pre = {0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](int s2, int l2, int bb2) {
+        const bf16x8 *xp = (const bf16x8 *)xrow(l2, bb2) + lane;
+#pragma unroll
+        for (int i = 0; i < XLOAD; ++i)
+            if (w + TDC_WAVES * i < XSTAGE) xpre[i] = xp[(size_t)(w + TDC_WAVES * i) * 64];
+        if (s2 > 0) {
+            const unsigned long long *src = xchp(bb2) + (size_t)((s2 + 1) & 1) * (NU * TDC_WAVES * 128);
+#ifndef TDC_DBG_NOPOLL
+#pragma unroll
+            for (int n = 0; n < NPOLL; ++n) gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+#pragma unroll
+            for (int n = 0; n < NPOLL; ++n) gr[n] = ((unsigned long long)(tag0 | (unsigned)s2) << 32) | 0x3c003c00u;
+#endif
+            if (nblk > 1) st_pre = *(const f32x4 *)cstp(bb2);   // a single block's state stays in registers (below)
+        }
+    };
+    prefetch(0, dir ? p.L - 1 : 0, gi);
+
+    int it = 0;
+    for (int s = 0; s < p.L; ++s) {
+        const int l = dir ? p.L - 1 - s : s;
+        for (int j = 0; j < nblk; ++j, ++it) {
+            const int bb = gi + j * p.ngroups, par = it & 1;
+            unsigned long long *xch = xchp(bb);
+            // A: this iteration's h_{s-1}: normally all there; a slower peer's granules are re-read until their tag matches
+            if (s > 0) {
+                const unsigned long long *src = xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128);
+                const unsigned want = tag0 | (unsigned)s;
+                int spins = 0;
+                while (!dead) {
+                    bool ok = true;
+#pragma unroll
+                    for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
+                    if (ok) break;
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int n = 0; n < NPOLL; ++n)
+                        if ((unsigned)(gr[n] >> 32) != want)
+                            gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int n = 0; n < NPOLL; ++n) {
+                    const int g = tid + 256 * n;
+                    const int e = g & 1, ln = (g >> 1) & 63, wp = (g >> 7) & 3, cp = g >> 9;
+                    *(unsigned *)(hbuf + (size_t)par * KH * TD_FRAG_BYTES + (size_t)(2 * cp + (wp >> 1)) * TD_FRAG_BYTES + ln * 16 +
+                                  8 * (wp & 1) + 4 * e) = (unsigned)gr[n];
+                }
+            }
+            {
+                bf16x8 *xd = (bf16x8 *)(xbuf + (size_t)par * XSTAGE * TD_FRAG_BYTES) + lane;
+#pragma unroll
+                for (int i = 0; i < XLOAD; ++i)
+                    if (w + TDC_WAVES * i < XSTAGE) xd[(size_t)(w + TDC_WAVES * i) * 64] = xpre[i];
+            }
+            f32x4 state = st_pre;
+            __syncthreads();     // h and x of this iteration are in LDS; the other parity's buffers are free again
+            // D: the next iteration's granules, inputs and state
+            if (j + 1 < nblk) prefetch(s, l, bb + p.ngroups);
+            else if (s + 1 < p.L) prefetch(s + 1, dir ? l - 1 : l + 1, gi);
+            // E: input projection + recurrent part
+            f32x16 acc = bias;
+            const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)par * XSTAGE * TD_FRAG_BYTES) + lane;
+            if constexpr (L0) {
+#pragma unroll
+                for (int kx = 0; kx < XF / 2; ++kx) {
+                    const bf16x8 xh = xs[(size_t)(2 * kx) * 64], xl = xs[(size_t)(2 * kx + 1) * 64];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx + 1], xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xh, acc, 0, 0, 0);
+                }
+            } else {
+                tdc_mfma_stream<XF, KH, NFR>(acc, W, xs);
+            }
+            if (s > 0) {
+                const bf16x8 *hs = (const bf16x8 *)(hbuf + (size_t)par * KH * TD_FRAG_BYTES) + lane;
+                tdc_mfma_stream<KH, 0, NFR>(acc, W, hs);
+            }
+            // F: gates, state, hand-off, outputs
+            tdc_finish_step<NU, GRU, SAVE>(p, acc, state, dead, nblk > 1 && s + 1 < p.L ? cstp(bb) : nullptr, xch, tag0, s, l, bb, dir, c, w,
+                                           lane);
+            if (nblk == 1) st_pre = state;
+        }
     }
 }
 
@@ -296,13 +475,17 @@ size_t td_cluster_packed_bytes(const TdRnnGeom &g, int layer0, int kx0) {
     return (size_t)g.nu * TDC_WAVES * tdc_slice_bytes(nfr);
 }
 
-// exchange scratch per direction: batch blocks x 2 parities x NU x 4 waves x 128 granules of 8 B
-size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb) { return (size_t)nbb * 2 * g.nu * TDC_WAVES * 128 * 8; }
+// scratch per direction: per batch block 2 parities x NU x 4 waves x 128 granules of 8 B (exchange), then NU x 4 waves x 64
+// lanes x 4 fp32 of recurrent state (all batch blocks' exchange buffers first, then all state)
+size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb) {
+    return (size_t)nbb * (2 * g.nu * TDC_WAVES * 128 * 8 + (size_t)g.nu * TDC_WAVES * 64 * 16);
+}
 
+#define TDC_CUS 256
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
-    // one workgroup per CU, all of them resident at once; tags carry 12 bits of step index; a parity buffer must have been
-    // rewritten by this launch before a step index of the previous launch can recur (L >= 4)
-    return g.nu == 8 && (size_t)g.nu * g.dirs * nbb <= 256 && L >= 4 && L < 4096;
+    // tags carry 12 bits of step index; a parity buffer must have been rewritten by this launch before a step index of the
+    // previous launch can recur (L >= 4).  Any batch: a cluster works its batch blocks one after the other within a step.
+    return g.nu == 8 && L >= 4 && L < 4096 && nbb >= 1;
 }
 
 int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, const float *const *w, char *dst, hipStream_t stream) {
@@ -318,6 +501,14 @@ int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, con
 
 template <int NU, int XF, bool L0>
 static int tdc_launch2(int gru, int save, const TdClusterParams &p, int blocks, hipStream_t stream) {
+    if (p.nbb > p.ngroups) {   // some cluster works two or more batch blocks: the pipelined kernel
+        if (!gru && !save) hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, false, false>), dim3(blocks), dim3(256), 0, stream, p);
+        else if (!gru) hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, false, true>), dim3(blocks), dim3(256), 0, stream, p);
+        else if (!save) hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, true, false>), dim3(blocks), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, true, true>), dim3(blocks), dim3(256), 0, stream, p);
+        TD_LAUNCH_CHECK();
+        return TD_OK;
+    }
     if (!gru && !save) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, false, false>), dim3(blocks), dim3(256), 0, stream, p);
     else if (!gru) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, false, true>), dim3(blocks), dim3(256), 0, stream, p);
     else if (!save) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, true, false>), dim3(blocks), dim3(256), 0, stream, p);
@@ -333,8 +524,13 @@ int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayer
     p.wpacked = wcluster; p.dir_stride = dir_stride;
     p.xin = lp.xin; p.out = lp.out; p.save = lp.save; p.save_dir_stride = lp.save_dir_stride;
     p.xch = xch; p.in_frags = lp.in_frags; p.out_frags = lp.out_frags; p.L = lp.L; p.nbb = lp.nbb; p.dirs = lp.dirs;
+    // the state scratch follows the exchange buffers of both directions
+    p.cstate = (float *)((char *)xch + (size_t)lp.dirs * lp.nbb * 2 * g.nu * TDC_WAVES * 128 * 8);
+    // one workgroup per CU, every one resident at once: at most 256 / (NU * dirs) clusters per direction
+    const int max_groups = TDC_CUS / (g.nu * lp.dirs);
+    p.ngroups = lp.nbb < max_groups ? lp.nbb : max_groups;
     p.epoch = (++g_cluster_epoch) & 0xFFFFFu;
-    const int blocks = g.nu * lp.dirs * lp.nbb;
+    const int blocks = g.nu * lp.dirs * p.ngroups;
     if (g.nu != 8) {
         td_set_error("cluster kernel: hidden block count %d is not instantiated", g.nu);
         return TD_ERR_UNSUPPORTED;
