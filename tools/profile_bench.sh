@@ -5,9 +5,9 @@ TAG=${1:-r1}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
-timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
+timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline --no-train-probe > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log" || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-probe > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log" || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 cd $ROOT
 DB=$(find "$OUT/trace" -name '*.db' | head -1)
 [ -n "$DB" ] && python3 tools/rocpd_stats.py "$DB" > "$OUT/kernel_stats.csv"
