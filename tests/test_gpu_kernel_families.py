@@ -192,8 +192,9 @@ def test_large_batch_chain_graph_equals_stepwise(dev):
 def test_cluster_family_forced(H, B, L, gru, shape, dev, knob):
     """Every instantiation of td_rnn_cluster_kernel (layer-0 input k-steps 1 / 2, one / two directions, LSTM / GRU,
     inference / saving): 8 workgroups per batch block and direction exchange h_t through L2 every step.  Forward against
-    the bf16-emulating oracle, saving forward == inference forward bit for bit, and the existing BPTT on the values
-    this kernel saved against the fp32 oracle's gradients."""
+    the bf16-emulating oracle, saving forward == inference forward bit for bit, and the cluster BPTT sweep
+    (td_bptt_cluster_kernel<8, LSTM / GRU>: partial sums of W_hh^T d a exchanged through L2) on the values this kernel
+    saved against the fp32 oracle's gradients."""
     from timediff_amd import _lib
     knob(_lib.LAYER_KERNEL_CLUSTER)
     dirs, Cc, n_num = (2, 14, 4) if shape == "bi_c14" else (1, 23, 7)
@@ -249,3 +250,29 @@ def test_cluster_dispatch_and_agreement(dev, knob):
     small = den_kernels(random_state(64, 14, 2, 2, 0, seed=1), dev)
     with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
         small.forward(cu(np.zeros((8, 14, 9), np.float32), dev), cu(np.zeros(8, np.int64), dev))
+
+
+@pytest.mark.parametrize("gru", [0, 1])
+def test_cluster_bptt_full_length_and_agreement(gru, dev, knob):
+    """The reference's training shape (micro-batch 32, L = 272, 3 bidirectional layers, H = 256) through the cluster BPTT
+    sweep: 271 hand-offs of bf16 partial sums per layer.  Gradients against the fp32 oracle (3 % of each tensor's
+    largest entry, as everywhere), and against td_bptt_sweep_kernel on the same saved values (both round d a to bf16;
+    the cluster also rounds its 8 partial sums of d h: 1 % of the largest entry)."""
+    from timediff_amd import _lib
+    B, L, Cc, n_num = 32, 272, 14, 4
+    sd = random_state(256, Cc, 3, 2, gru, seed=41 + gru)
+    den = den_kernels(sd, dev)
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=77)
+    gy = (rng.standard_normal((B, Cc, L)) / (B * L)).astype(np.float32)
+    film = den.time_film(cu(t, dev))
+    grads = {}
+    for mode in (_lib.LAYER_KERNEL_CLUSTER, _lib.LAYER_KERNEL_UNITS):
+        knob(mode)
+        den.forward_train(cu(x, dev), film)
+        g_layer, g_misc, _ = den.backward(cu(gy, dev), film)
+        grads[mode] = [g.cpu().numpy().copy() for g in g_layer]
+    _, _, ref = orc.Denoiser(sd).backward(x, t, gy)
+    for key, a, b in zip(den._lkeys, grads[_lib.LAYER_KERNEL_CLUSTER], grads[_lib.LAYER_KERNEL_UNITS]):
+        assert np.isfinite(a).all(), key
+        assert _rel(a, ref[key]) < 3e-2, (key, _rel(a, ref[key]))
+        assert _rel(a, b) < 1e-2, (key, _rel(a, b))

@@ -1,0 +1,36 @@
+// Shared by the cluster-persistent kernels (rnn_cluster.hip: forward; rnn_cluster_bwd.hip: BPTT sweep): the hand-off
+// between the workgroups of a cluster goes through L2 as 8-byte {payload, tag} granules, written and read with relaxed
+// agent-scope 64-bit atomics (self-validating: no flag, no fence).  tag = (launch epoch << 12) | (step + 1).
+#pragma once
+#include "rnn_geom.h"
+
+#define TDC_WAVES 4
+#define TDC_SPIN_LIMIT (1 << 22)
+#define TDC_CUS 256
+
+__device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsigned tag) {
+    return ((unsigned long long)tag << 32) | payload;
+}
+
+unsigned td_cluster_next_epoch(void);   // rnn_cluster.hip: one counter for every cluster launch of the process (20 bits)
+
+// ---- BPTT sweep of one layer by the cluster (rnn_cluster_bwd.hip) ------------------------------------------------------
+struct TdClusterBwdParams {
+    const char *gsrc[2];     // gradient w.r.t. this layer's output (fragments), n_src of them are summed
+    int n_src;
+    const float *save;       // [dir][l][bblk][NU][5][64][16] fp32
+    size_t save_dir;         // floats
+    char *daf;               // [dir][l][bblk][4][KH] fragments
+    size_t daf_dir;          // bytes
+    __bf16 *dapl;            // [dir][4][hpad][L * Bp]
+    size_t dapl_dir;         // elements
+    const char *wt;          // W_hh^T fragments [rb][nterm][KH] (td_pack_weights_T_kernel), direction 0
+    size_t wt_dir;           // bytes
+    unsigned long long *inbox;   // [dir][bblk][parity][dst c'][src c][wave][lane][2] granules
+    int L, nbb, dirs, out_frags;
+    unsigned epoch;
+};
+
+bool td_bptt_cluster_supported(const TdRnnGeom &g, int nbb, int L);
+size_t td_bptt_cluster_inbox_bytes(const TdRnnGeom &g, int nbb);
+int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, hipStream_t stream);   // sets p.epoch

@@ -23,11 +23,8 @@
 //
 // Activations in and out, and the values saved for the backward pass, use the layouts of the other kernel families
 // (rnn_layout.h, rnn_params.h): the cluster kernel is a drop-in per layer launch.
-#include "rnn_geom.h"
+#include "rnn_cluster.h"
 #include "rnn_params.h"
-
-#define TDC_WAVES 4
-#define TDC_SPIN_LIMIT (1 << 22)
 
 // packed weights of one (layer, direction): [c (NU)][wave (4)] slices, each = 64 lanes x 16 fp32 bias (4 KiB) followed by
 // NFR fragments of 1 KiB (bf16): KH recurrent k-steps, then the input k-steps (layer 0: hi, lo per 16 channels)
@@ -112,10 +109,6 @@ struct TdClusterParams {
     int ngroups;              // clusters per direction; cluster gi works the batch blocks gi, gi + ngroups, ...
     unsigned epoch;
 };
-
-__device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsigned tag) {
-    return ((unsigned long long)tag << 32) | payload;
-}
 
 // acc += sum_f W[w0 + f] x (B fragment f of `src`), f < NF: the B fragments come from LDS through a register ring RD deep,
 // each read issued RD MFMAs ahead of its use.  Left to the compiler the reads share one register quad and every MFMA waits
@@ -469,6 +462,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
 // host side
 // ---------------------------------------------------------------------------------------------
 static unsigned g_cluster_epoch = 0;
+unsigned td_cluster_next_epoch(void) { return (++g_cluster_epoch) & 0xFFFFFu; }
 
 size_t td_cluster_packed_bytes(const TdRnnGeom &g, int layer0, int kx0) {
     const int nfr = g.kh + (layer0 ? 2 * kx0 : g.dirs * g.kh);
@@ -481,7 +475,6 @@ size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb) {
     return (size_t)nbb * (2 * g.nu * TDC_WAVES * 128 * 8 + (size_t)g.nu * TDC_WAVES * 64 * 16);
 }
 
-#define TDC_CUS 256
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
     // tags carry 12 bits of step index; a parity buffer must have been rewritten by this launch before a step index of the
     // previous launch can recur (L >= 4).  Any batch: a cluster works its batch blocks one after the other within a step.
@@ -529,7 +522,7 @@ int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayer
     // one workgroup per CU, every one resident at once: at most 256 / (NU * dirs) clusters per direction
     const int max_groups = TDC_CUS / (g.nu * lp.dirs);
     p.ngroups = lp.nbb < max_groups ? lp.nbb : max_groups;
-    p.epoch = (++g_cluster_epoch) & 0xFFFFFu;
+    p.epoch = td_cluster_next_epoch();
     const int blocks = g.nu * lp.dirs * p.ngroups;
     if (g.nu != 8) {
         td_set_error("cluster kernel: hidden block count %d is not instantiated", g.nu);

@@ -6,10 +6,12 @@
 //   per layer, top down:
 //     bptt_sweep  ONE launch for all steps: gate-gradient arithmetic (d a_t as MFMA fragments + plain rows) and
 //                 d h_{t-1} = W_hh^T d a_t on MFMA, state in registers, d a_t exchanged through LDS
+//                 (small batches at H in (224, 256]: td_bptt_cluster_kernel, rnn_cluster_bwd.hip, 8 workgroups per
+//                 batch block and direction with W_hh^T resident in registers)
 //     frag_gemm   all steps at once: d x = W_ih^T d a         (gradient for the layer below)
 //     dw_gemm     d W = d a . [x ; h_prev]^T over all (sequence, step) columns   (MFMA, split-K, fp32 atomics)
 //     bias_reduce d b = row sums of d a
-#include "rnn_geom.h"
+#include "rnn_cluster.h"
 #include "rnn_launch.h"
 
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
@@ -17,6 +19,7 @@ int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, i
 }
 
 size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);   // rnn_cluster.hip
+int td_layer_kernel_mode(void);   // api.cpp
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
                          char *const *acts, float *const *saves, float *state, hipStream_t stream);
 // gemm_lib.cpp (rocBLAS)
@@ -32,7 +35,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // ---------------------------------------------------------------------------------------------
 struct TdTrainLayout {
     int nbb, Bp, cpad;      // batch blocks, padded batch, layer-0 channels padded to 32
-    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dhrec[2], dc[2], total;
+    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, total;
     size_t act_bytes, save_dir_floats, daf_bytes, dapl_slab_elems, cols;
 };
 
@@ -60,12 +63,12 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
             t.daf[l][d] = take(t.daf_bytes);
             t.dapl[l][d] = take(4 * t.dapl_slab_elems * 2);
         }
-    for (int d = 0; d < 2; ++d) t.dhrec[d] = take((size_t)t.nbb * g.kh * TD_FRAG_BYTES);
     {   // back to back (a multiple of 256 B each); the forward pass uses the pair as the layer kernels' state / exchange scratch
         size_t dcb = (size_t)t.nbb * g.nu * 1024 * sizeof(float);
         if (g.nu == TD_CLUSTER_NU && td_cluster_xch_dir_bytes(g, t.nbb) > dcb) dcb = td_cluster_xch_dir_bytes(g, t.nbb);
         for (int d = 0; d < 2; ++d) t.dc[d] = take(dcb);
     }
+    t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));   // the cluster BPTT sweep's partial-sum exchange (small batches only)
     t.total = off;
     return t;
 }
@@ -393,96 +396,17 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// BPTT step, elementwise part: one wave per (direction, batch block, unit block)
+// operands of a layer's BPTT sweep
 // ---------------------------------------------------------------------------------------------
 struct TdBpttParams {
     const char *gsrc[2];     // gradient w.r.t. this layer's output (fragments), n_src of them are summed
     int n_src;
-    const char *dhrec;       // [dir][bblk][KH] fragments: W_hh^T d a of the step processed before (or unused)
-    float *dc;               // [dir][bblk][NU][64][16]  LSTM: d c carried ; GRU: z * d h carried
     const float *save;       // [dir][l][bblk][NU][5][64][16]
     char *daf;               // [dir][l][bblk][4][KH] fragments
     __bf16 *dapl;            // [dir][4][hpad][L*Bp]
-    size_t dhrec_dir, dc_dir, save_dir, daf_dir, dapl_dir;   // direction strides (bytes / floats / bytes / bytes / elems)
-    int s, L, nbb, nu, kh, dirs, out_frags, gru;
+    size_t save_dir, daf_dir, dapl_dir;   // direction strides (floats / bytes / elems)
+    int L, nbb, nu, kh, dirs, out_frags, gru;
 };
-
-__global__ __launch_bounds__(64) void td_bptt_point_kernel(TdBpttParams p) {
-    const int u = blockIdx.x, bblk = blockIdx.y, d = blockIdx.z, lane = threadIdx.x;
-    const int hf = lane >> 5, m = lane & 31;
-    // BPTT visits this direction's steps in reverse processing order
-    const int pos = p.L - 1 - p.s;                 // position in the direction's forward order
-    const int l = d ? p.L - 1 - pos : pos;
-    const int lprev = d ? l + 1 : l - 1;           // the step processed before l in the forward pass
-    const bool has_prev = pos > 0, first = p.s == 0;
-    float dh[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-    for (int sidx = 0; sidx < p.n_src; ++sidx) {
-        const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-        const bf16x8 a = gp[0], b = gp[64];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { dh[j] += (float)a[j]; dh[8 + j] += (float)b[j]; }
-    }
-    float *dcp = p.dc + (size_t)d * p.dc_dir + (((size_t)bblk * p.nu + u) * 64 + lane) * 16;
-    float carry[16];
-    if (!first) {
-        const bf16x8 *rp = (const bf16x8 *)(p.dhrec + (size_t)d * p.dhrec_dir + ((size_t)bblk * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-        const bf16x8 a = rp[0], b = rp[64];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { dh[j] += (float)a[j]; dh[8 + j] += (float)b[j]; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) carry[r] = dcp[r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) carry[r] = 0.f;
-    }
-    const float *sv = p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16;
-    const float *svp = p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16;
-    float da[4][16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float prev = has_prev ? svp[r] : 0.f;   // c_{t-1} (LSTM) / h_{t-1} (GRU)
-        if (!p.gru) {
-            const float ig = sv[r], fg = sv[1024 + r], gg = sv[2048 + r], og = sv[3072 + r], cv = sv[4096 + r];
-            const float tc = td_tanh(cv);
-            const float dcv = carry[r] + dh[r] * og * (1.0f - tc * tc);
-            da[0][r] = dcv * gg * ig * (1.0f - ig);
-            da[1][r] = dcv * prev * fg * (1.0f - fg);
-            da[2][r] = dcv * ig * (1.0f - gg * gg);
-            da[3][r] = dh[r] * tc * og * (1.0f - og);
-            carry[r] = dcv * fg;
-        } else {
-            const float rg = sv[r], zg = sv[1024 + r], ng = sv[2048 + r], hn = sv[3072 + r];
-            const float dht = dh[r] + carry[r];
-            const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
-            da[0][r] = dan * hn * rg * (1.0f - rg);
-            da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
-            da[2][r] = dan;
-            da[3][r] = dan * rg;
-            carry[r] = dht * zg;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dcp[r] = carry[r];
-    const size_t cols = (size_t)p.L * p.nbb * 32;
-    const int hpad = p.kh * 16;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bf16x8 a, b;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)da[g][j]; b[j] = (__bf16)da[g][8 + j]; }
-        bf16x8 *fp = (bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + g) * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-        fp[0] = a;
-        fp[64] = b;
-        __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)g * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int unit = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            pl[(size_t)unit * cols] = r < 8 ? a[r] : b[r - 8];
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // fragment GEMM: out[tile][2 rb + {0,1}] = sum_{term, ks} WT[rb][term][ks] x in[tile][slab(term) * KH + ks]
@@ -529,7 +453,7 @@ __global__ __launch_bounds__(256) void td_frag_gemm_kernel(TdFragGemmParams p) {
 // d a_t also goes to HBM in both layouts the batched GEMMs after the sweep read (d x = W_ih^T d a, d W).
 // ---------------------------------------------------------------------------------------------
 struct TdSweepParams {
-    TdBpttParams b;          // b.s unused
+    TdBpttParams b;
     const char *wt;          // W_hh^T fragments [rb][nterm][kh], direction 0
     size_t wt_dir;           // bytes to direction 1
     int nterm;
@@ -788,14 +712,23 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
             TdSweepParams q;
             TdBpttParams &p = q.b;
             p.gsrc[0] = ws + t.gout[l][0]; p.gsrc[1] = ws + t.gout[l][1]; p.n_src = n_src;
-            p.dhrec = nullptr; p.dhrec_dir = 0; p.dc = nullptr; p.dc_dir = 0;
             p.save = (const float *)(ws + t.save[l]); p.save_dir = t.save_dir_floats;
             p.daf = ws + t.daf[l][0]; p.daf_dir = D > 1 ? t.daf[l][1] - t.daf[l][0] : 0;
             p.dapl = (__bf16 *)(ws + t.dapl[l][0]); p.dapl_dir = D > 1 ? (t.dapl[l][1] - t.dapl[l][0]) / 2 : 0;
-            p.s = 0; p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
+            p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
             q.wt = wT; q.wt_dir = packT_dir; q.nterm = G;
             q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
-            if (g.nu <= 8) {
+            const int mode = td_layer_kernel_mode();
+            if ((mode == TD_LAYER_KERNEL_AUTO || mode == TD_LAYER_KERNEL_CLUSTER) && td_bptt_cluster_supported(g, t.nbb, L)) {
+                TdClusterBwdParams cp;
+                cp.gsrc[0] = p.gsrc[0]; cp.gsrc[1] = p.gsrc[1]; cp.n_src = n_src;
+                cp.save = p.save; cp.save_dir = p.save_dir; cp.daf = p.daf; cp.daf_dir = p.daf_dir;
+                cp.dapl = p.dapl; cp.dapl_dir = p.dapl_dir; cp.wt = wT; cp.wt_dir = packT_dir;
+                cp.inbox = (unsigned long long *)(ws + t.inbox);
+                cp.L = L; cp.nbb = t.nbb; cp.dirs = D; cp.out_frags = KT;
+                rc = td_launch_bptt_cluster(cfg->gru, g, cp, stream);
+                if (rc != TD_OK) return rc;
+            } else if (g.nu <= 8) {
                 const size_t shm = (size_t)2 * 4 * g.kh * TD_FRAG_BYTES;
                 TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
                 hipLaunchKernelGGL((td_bptt_sweep_kernel<1, false>), dim3(t.nbb, D), dim3(512), shm, stream, q);
