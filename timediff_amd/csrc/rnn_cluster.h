@@ -27,7 +27,8 @@ struct TdClusterBwdParams {
     const char *wt;          // W_hh^T fragments [rb][nterm][KH] (td_pack_weights_T_kernel), direction 0
     size_t wt_dir;           // bytes
     unsigned long long *inbox;   // [dir][bblk][parity][dst c'][src c][wave][lane][2] granules
-    int L, nbb, dirs, out_frags;
+    float *db_ih[2], *db_hh[2];  // per direction: bias gradients (accumulated): row sums of d a over steps and sequences
+    int L, nbb, dirs, out_frags, H;
     unsigned epoch;
 };
 

@@ -73,6 +73,11 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
     prefetch(0);
 
     f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+    float dbacc[4][4];           // bias gradients: d a summed over the steps per lane, over the 32 sequences at the end
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dbacc[gi][i] = 0.f;
     bool dead = false;
     for (int s = 0; s < p.L; ++s) {
         const int l = lpos(s), par = s & 1;
@@ -142,6 +147,10 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
 #pragma unroll
                 for (int i = 0; i < 4; ++i) da[gi][i] = __builtin_nanf("");
         }
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dbacc[gi][i] += da[gi][i];
         // ---- d a_t: to LDS for the cluster's product, to HBM for the batched GEMMs after the sweep -----------------------------
         {
             char *fbase = p.daf + (size_t)dir * p.daf_dir + (((size_t)l * p.nbb + bb) * 4 * KH + kfrag) * TD_FRAG_BYTES + sub;
@@ -197,6 +206,27 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
             }
         }
     }
+    // ---- bias gradients ---------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = dbacc[gi][i];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            const int unit = 32 * c + 8 * w + 4 * hf + i;
+            if (m == 0 && unit < p.H) {
+                float *bi = p.db_ih[dir], *bh = p.db_hh[dir];
+                if (!GRU || gi < 2) {
+                    atomicAdd(&bi[gi * p.H + unit], t);
+                    atomicAdd(&bh[gi * p.H + unit], t);
+                } else if (gi == 2) {
+                    atomicAdd(&bi[2 * p.H + unit], t);
+                } else {
+                    atomicAdd(&bh[2 * p.H + unit], t);
+                }
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@
 //                 batch block and direction with W_hh^T resident in registers)
 //     frag_gemm   all steps at once: d x = W_ih^T d a         (gradient for the layer below)
 //     dw_gemm     d W = d a . [x ; h_prev]^T over all (sequence, step) columns   (MFMA, split-K, fp32 atomics)
-//     bias_reduce d b = row sums of d a
+//     bias_reduce d b = row sums of d a   (H > 256 only: the sweeps up to 256 accumulate them in registers)
 #include "rnn_cluster.h"
 #include "rnn_launch.h"
 
@@ -35,7 +35,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // ---------------------------------------------------------------------------------------------
 struct TdTrainLayout {
     int nbb, Bp, cpad;      // batch blocks, padded batch, layer-0 channels padded to 32
-    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, total;
+    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, total;
     size_t act_bytes, save_dir_floats, daf_bytes, dapl_slab_elems, cols;
 };
 
@@ -68,6 +68,8 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
         if (g.nu == TD_CLUSTER_NU && td_cluster_xch_dir_bytes(g, t.nbb) > dcb) dcb = td_cluster_xch_dir_bytes(g, t.nbb);
         for (int d = 0; d < 2; ++d) t.dc[d] = take(dcb);
     }
+    t.chan = take((size_t)L * t.nbb * (cfg->c_out + 1) * 32 * sizeof(float));   // head backward: g * rstd per channel, mu
+    t.g1 = take((size_t)batch * cfg->c_out * sizeof(float));
     t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));   // the cluster BPTT sweep's partial-sum exchange (small batches only)
     t.total = off;
     return t;
@@ -237,6 +239,8 @@ struct TdHeadBwdParams {
     const char *act;
     const float *ln_w, *ln_b, *fc_w, *film, *gy;
     char *gout;                                   // d h_top fragments (same layout as act)
+    float *chan;                                  // [l][bblk][c_out + 1][32]: g[c] * rstd per output channel, then mu
+    float *g1;                                    // [B][c_out]: sum over l of grad_y
     float *d_film, *d_ln_w, *d_ln_b, *d_fc_w, *d_fc_b;  // accumulated (atomics)
     int B, L, nbb, H, hpad, kh, dirs, c_out;
 };
@@ -248,35 +252,36 @@ __device__ __forceinline__ float td_half_wave_sum(float x) {
     return x;
 }
 
-// ROG: the read-only parameter copies (LayerNorm affine, fc_w) stay in global memory / L2 instead of LDS, which then
-// holds only the accumulators: (2 + CMAX) * D * Hpad floats (wide hidden sizes)
+// The head is y = fc(FiLM(LayerNorm(h))) per position (blocks.py:336-341).  Its backward pass in three kernels, none of
+// which reduces anything per position across lanes or through atomics (the first version did both: 570 M global
+// atomics at batch 2048, 14 ms):
+//   td_head_bwd_dh_kernel     per position: LayerNorm statistics, d h (fragments), and g[c] * rstd, mu laid out per
+//                             (step, batch block, channel) for the kernel below
+//   td_rowsum_kernel          G1[b][c] = sum_l grad_y[b][c][l]
+//   td_head_bwd_param_kernel  a wave owns (batch block, 16-unit fragment) and walks the steps, accumulating per lane
+//                                 X[c][f] = sum_l g[c] * rstd * (h[f] - mu)     ( = sum_l g[c] * xhat[f] )
+//                             in registers; every parameter gradient is a combination of X and G1 (derivation in
+//                             DESIGN.md section 4.4), reduced over the 32 sequences ONCE, at the end.
+
+// ROG: LayerNorm weight and fc_w are read from global memory / L2 instead of LDS (wide hidden sizes with many channels)
 template <int CMAX, bool ROG>
-__global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
+__global__ __launch_bounds__(256) void td_head_bwd_dh_kernel(TdHeadBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float hl[];
     const int DHP = p.dirs * p.hpad, DH = p.dirs * p.H;
-    float *s_lnw = hl, *s_lnb = hl + DHP, *s_fcw = hl + 2 * DHP;
-    float *a_lnw = ROG ? hl : s_fcw + CMAX * DHP, *a_lnb = a_lnw + DHP, *a_fcw = a_lnb + DHP, *a_fcb = a_fcw + CMAX * DHP;
-    for (int i = threadIdx.x; i < DHP; i += 256) {
-        const int d = i / p.hpad, unit = i % p.hpad;
-        const bool ok = unit < p.H;
-        if constexpr (!ROG) {
+    float *s_lnw = hl, *s_fcw = hl + DHP;
+    if constexpr (!ROG) {
+        for (int i = threadIdx.x; i < DHP; i += 256) {
+            const int d = i / p.hpad, unit = i % p.hpad;
+            const bool ok = unit < p.H;
             s_lnw[i] = ok ? p.ln_w[d * p.H + unit] : 0.f;
-            s_lnb[i] = ok ? p.ln_b[d * p.H + unit] : 0.f;
+            for (int c = 0; c < CMAX; ++c) s_fcw[c * DHP + i] = (ok && c < p.c_out) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
         }
-        a_lnw[i] = 0.f; a_lnb[i] = 0.f;
-        for (int c = 0; c < CMAX; ++c) {
-            if constexpr (!ROG) s_fcw[c * DHP + i] = (ok && c < p.c_out) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
-            a_fcw[c * DHP + i] = 0.f;
-        }
+        __syncthreads();
     }
-    // parameter reads for a valid unit (ip: padded index, feat: index in the parameter tensors)
     auto lnw = [&](int ip, int feat) { return ROG ? p.ln_w[feat] : s_lnw[ip]; };
-    auto lnb = [&](int ip, int feat) { return ROG ? p.ln_b[feat] : s_lnb[ip]; };
     auto fcw = [&](int c, int ip, int feat) { return ROG ? (c < p.c_out ? p.fc_w[(size_t)c * DH + feat] : 0.f) : s_fcw[c * DHP + ip]; };
-    if (threadIdx.x < CMAX) a_fcb[threadIdx.x] = 0.f;
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
-    const int KT = p.dirs * p.kh;
+    const int KT = p.dirs * p.kh, CH = p.c_out + 1;
     const size_t ntask = (size_t)p.L * p.nbb;
     for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
         const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
@@ -306,10 +311,15 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
         float g[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) g[c] = (valid && c < p.c_out) ? p.gy[((size_t)b * p.c_out + c) * p.L + l] : 0.f;
+        if (hf == 0) {
+            float *cp = p.chan + task * CH * 32 + m;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < p.c_out) cp[c * 32] = g[c] * rstd;
+            cp[p.c_out * 32] = mu;
+        }
         const float *film = p.film + (size_t)(valid ? b : 0) * 2 * DH;
-        float *dfilm = p.d_film + (size_t)(valid ? b : 0) * 2 * DH;
-
-        // pass A: parameter gradients and the two LayerNorm-backward means
+        // the two means of the LayerNorm backward
         float m1 = 0.f, m2 = 0.f;
         for (int ks = 0; ks < KT; ++ks) {
             const bf16x8 v = fp[ks * 64];
@@ -319,47 +329,19 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
                 const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
                 if (unit >= p.H) continue;
                 const int ip = d * p.hpad + unit, feat = d * p.H + unit;
-                const float xh = ((float)v[j] - mu) * rstd;
-                const float lnout = xh * lnw(ip, feat) + lnb(ip, feat);
-                const float sc1 = film[feat] + 1.0f;
-                const float yf = lnout * sc1 + film[DH + feat];
                 float dyf = 0.f;
 #pragma unroll
-                // The 32 sequences of a half-wave share this feature, i.e. the same accumulator: summed across the lanes
-                // first (an invalid sequence holds g = 0 and adds nothing), then ONE lane adds -- 32 lanes adding into
-                // one LDS word serialise (the head backward took 30.8 ms at batch 2048 that way).
-                for (int c = 0; c < CMAX; ++c) {
-                    dyf += g[c] * fcw(c, ip, feat);
-                    if (c < p.c_out) {
-                        const float tot = td_half_wave_sum(g[c] * yf);
-                        if (m == 0) atomicAdd(&a_fcw[c * DHP + ip], tot);
-                    }
-                }
-                const float dln = dyf * sc1;
-                const float t_lnw = td_half_wave_sum(dln * xh), t_lnb = td_half_wave_sum(dln);
-                if (m == 0) {
-                    atomicAdd(&a_lnw[ip], t_lnw);
-                    atomicAdd(&a_lnb[ip], t_lnb);
-                }
-                if (valid) {
-                    atomicAdd(&dfilm[feat], dyf * lnout);
-                    atomicAdd(&dfilm[DH + feat], dyf);
-                    const float dxh = dln * lnw(ip, feat);
-                    m1 += dxh;
-                    m2 += dxh * xh;
-                }
+                for (int c = 0; c < CMAX; ++c) dyf += g[c] * fcw(c, ip, feat);
+                const float dxh = dyf * (film[feat] + 1.0f) * lnw(ip, feat);
+                m1 += dxh;
+                m2 += dxh * (((float)v[j] - mu) * rstd);
             }
-        }
-        if (hf == 0 && valid) {
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < p.c_out) atomicAdd(&a_fcb[c], g[c]);
         }
         m1 += __shfl_xor(m1, 32);
         m2 += __shfl_xor(m2, 32);
         m1 /= (float)DH;
         m2 /= (float)DH;
-        // pass B: d h
+        // d h
         bf16x8 *op = (bf16x8 *)(p.gout + task * KT * TD_FRAG_BYTES) + lane;
         for (int ks = 0; ks < KT; ++ks) {
             const bf16x8 v = fp[ks * 64];
@@ -383,16 +365,96 @@ __global__ __launch_bounds__(256) void td_head_bwd_kernel(TdHeadBwdParams p) {
             op[ks * 64] = o;
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < DHP; i += 256) {
-        const int d = i / p.hpad, unit = i % p.hpad;
-        if (unit >= p.H) continue;
-        const int feat = d * p.H + unit;
-        atomicAdd(&p.d_ln_w[feat], a_lnw[i]);
-        atomicAdd(&p.d_ln_b[feat], a_lnb[i]);
-        for (int c = 0; c < p.c_out; ++c) atomicAdd(&p.d_fc_w[(size_t)c * DH + feat], a_fcw[c * DHP + i]);
+}
+
+// G1[row] = sum of the row's L entries (rows = B * c_out rows of grad_y), one wave per row
+__global__ __launch_bounds__(256) void td_rowsum_kernel(const float *__restrict__ x, float *__restrict__ out, int rows, int L) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int l = lane; l < L; l += 64) s += x[(size_t)row * L + l];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = s;
+}
+
+// wave = (batch block blockIdx.x, fragment blockIdx.y * 4 + wave, channels [NC * blockIdx.z, + NC))
+template <int NC>
+__global__ __launch_bounds__(256, 2) void td_head_bwd_param_kernel(TdHeadBwdParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
+    const int KT = p.dirs * p.kh, CH = p.c_out + 1, DH = p.dirs * p.H;
+    const int bblk = blockIdx.x, ks = blockIdx.y * 4 + wave, c0 = blockIdx.z * NC;
+    if (ks >= KT) return;
+    const int b = bblk * 32 + m;
+    const bool valid = b < p.B;
+    float X[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) X[c][j] = 0.f;
+    const bf16x8 *fp = (const bf16x8 *)(p.act + ((size_t)bblk * KT + ks) * TD_FRAG_BYTES) + lane;
+    const float *cp = p.chan + (size_t)bblk * CH * 32 + m;
+    const size_t fstep = (size_t)p.nbb * KT * 64, cstep = (size_t)p.nbb * CH * 32;
+    int coff[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) coff[c] = (c0 + c < p.c_out ? c0 + c : p.c_out - 1) * 32;
+#pragma unroll 2
+    for (int l = 0; l < p.L; ++l) {
+        const bf16x8 v = fp[(size_t)l * fstep];
+        const float *cl = cp + (size_t)l * cstep;
+        const float mu = cl[p.c_out * 32];
+        float gr[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gr[c] = cl[coff[c]];   // rows beyond c_out repeat the last channel and are ignored below
+        float hc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hc[j] = (float)v[j] - mu;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) X[c][j] = __builtin_fmaf(gr[c], hc[j], X[c][j]);
     }
-    if ((int)threadIdx.x < p.c_out) atomicAdd(&p.d_fc_b[threadIdx.x], a_fcb[threadIdx.x]);
+    float G1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) G1[c] = (valid && c0 + c < p.c_out) ? p.g1[(size_t)b * p.c_out + c0 + c] : 0.f;
+    const float *film = p.film + (size_t)(valid ? b : 0) * 2 * DH;
+    float *dfilm = p.d_film + (size_t)(valid ? b : 0) * 2 * DH;
+    const int d = ks / p.kh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+        if (unit >= p.H) continue;     // uniform over the half-wave
+        const int feat = d * p.H + unit;
+        const float lw = p.ln_w[feat], lb = p.ln_b[feat];
+        const float sc1 = film[feat] + 1.0f, sh = film[DH + feat];
+        float sx = 0.f, sg = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c0 + c >= p.c_out) continue;
+            const float fw = p.fc_w[(size_t)(c0 + c) * DH + feat];
+            sx += fw * X[c][j];
+            sg += fw * G1[c];
+            // d fc_w[c][f] = sum over positions of g[c] * (lnout * (1 + scale) + shift)
+            const float t = td_half_wave_sum(sc1 * (lw * X[c][j] + lb * G1[c]) + sh * G1[c]);
+            if (m == 0) atomicAdd(&p.d_fc_w[(size_t)(c0 + c) * DH + feat], t);
+        }
+        if (valid) {
+            atomicAdd(&dfilm[feat], lw * sx + lb * sg);     // d scale = sum_l dyf * lnout
+            atomicAdd(&dfilm[DH + feat], sg);               // d shift = sum_l dyf
+        }
+        const float t_lnw = td_half_wave_sum(sc1 * sx), t_lnb = td_half_wave_sum(sc1 * sg);
+        if (m == 0) {
+            atomicAdd(&p.d_ln_w[feat], t_lnw);
+            atomicAdd(&p.d_ln_b[feat], t_lnb);
+        }
+    }
+    if (ks == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float t = td_half_wave_sum(G1[c]);
+            if (lane == 0 && c0 + c < p.c_out) atomicAdd(&p.d_fc_b[c0 + c], t);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,7 +467,8 @@ struct TdBpttParams {
     char *daf;               // [dir][l][bblk][4][KH] fragments
     __bf16 *dapl;            // [dir][4][hpad][L*Bp]
     size_t save_dir, daf_dir, dapl_dir;   // direction strides (floats / bytes / elems)
-    int L, nbb, nu, kh, dirs, out_frags, gru;
+    float *db_ih[2], *db_hh[2];   // per direction: bias gradients (accumulated; the single-block-per-wave sweeps fold the row sums of d a in)
+    int L, nbb, nu, kh, dirs, out_frags, gru, H;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -452,6 +515,21 @@ __global__ __launch_bounds__(256) void td_frag_gemm_kernel(TdFragGemmParams p) {
 //     d h_{t-1}[its row blocks] = W_hh^T (A fragments, L2-resident) x d a_t
 // d a_t also goes to HBM in both layouts the batched GEMMs after the sweep read (d x = W_ih^T d a, d W).
 // ---------------------------------------------------------------------------------------------
+// slab gi of d a is the gradient of which bias rows: LSTM i, f, g, o of both; GRU r, z of both, n_x of b_ih, n_h of b_hh
+__device__ __forceinline__ void td_bias_add(float *db_ih, float *db_hh, int gru, int H, int gi, int unit, float v) {
+    if (!gru) {
+        atomicAdd(&db_ih[gi * H + unit], v);
+        atomicAdd(&db_hh[gi * H + unit], v);
+    } else if (gi < 2) {
+        atomicAdd(&db_ih[gi * H + unit], v);
+        atomicAdd(&db_hh[gi * H + unit], v);
+    } else if (gi == 2) {
+        atomicAdd(&db_ih[2 * H + unit], v);
+    } else {
+        atomicAdd(&db_hh[2 * H + unit], v);
+    }
+}
+
 struct TdSweepParams {
     TdBpttParams b;
     const char *wt;          // W_hh^T fragments [rb][nterm][kh], direction 0
@@ -477,6 +555,14 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
     for (int i = 0; i < UPW; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { dh[i][k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[i][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // bias gradients = sums of d a over steps and sequences: per lane here, over the 32 sequences at the end
+    float dbacc[WIDE ? 1 : 4][16];
+    if constexpr (!WIDE) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dbacc[gi][r] = 0.f;
+    }
 
     for (int s = 0; s < p.L; ++s) {
         const int pos = p.L - 1 - s;                   // position in the direction's forward order
@@ -497,54 +583,58 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
             }
             const f32x4 *sv = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16);
             const f32x4 *svp = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16);
-            float da[4][16];
+            // two halves of the unit block (accumulator rows 0..7 / 8..15 = one 16-byte fragment row each): d a lives for
+            // half a block at a time
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 s0 = sv[k], s1 = sv[256 + k], s2 = sv[512 + k], s3 = sv[768 + k], s4 = sv[1024 + k];
-                const f32x4 pv = has_prev ? svp[k] : f32x4{0.f, 0.f, 0.f, 0.f};   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+            for (int half = 0; half < 2; ++half) {
+                float da[4][8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * k + e;
-                    const float g = dh[i][k][e], prev = pv[e];
-                    if (!p.gru) {
-                        const float ig = s0[e], fg = s1[e], gg = s2[e], og = s3[e], cv = s4[e];
-                        const float tc = td_tanh(cv);
-                        const float dcv = carry[i][k][e] + g * og * (1.0f - tc * tc);
-                        da[0][r] = dcv * gg * ig * (1.0f - ig);
-                        da[1][r] = dcv * prev * fg * (1.0f - fg);
-                        da[2][r] = dcv * ig * (1.0f - gg * gg);
-                        da[3][r] = g * tc * og * (1.0f - og);
-                        carry[i][k][e] = dcv * fg;
-                    } else {
-                        const float rg = s0[e], zg = s1[e], ng = s2[e], hn = s3[e];
-                        const float dht = g + carry[i][k][e];
-                        const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
-                        da[0][r] = dan * hn * rg * (1.0f - rg);
-                        da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
-                        da[2][r] = dan;
-                        da[3][r] = dan * rg;
-                        carry[i][k][e] = dht * zg;
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int k = 2 * half + kk;
+                    const f32x4 s0 = sv[k], s1 = sv[256 + k], s2 = sv[512 + k], s3 = sv[768 + k], s4 = sv[1024 + k];
+                    const f32x4 pv = has_prev ? svp[k] : f32x4{0.f, 0.f, 0.f, 0.f};   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * kk + e;
+                        const float g = dh[i][k][e], prev = pv[e];
+                        if (!p.gru) {
+                            const float ig = s0[e], fg = s1[e], gg = s2[e], og = s3[e], cv = s4[e];
+                            const float tc = td_tanh(cv);
+                            const float dcv = carry[i][k][e] + g * og * (1.0f - tc * tc);
+                            da[0][r] = dcv * gg * ig * (1.0f - ig);
+                            da[1][r] = dcv * prev * fg * (1.0f - fg);
+                            da[2][r] = dcv * ig * (1.0f - gg * gg);
+                            da[3][r] = g * tc * og * (1.0f - og);
+                            carry[i][k][e] = dcv * fg;
+                        } else {
+                            const float rg = s0[e], zg = s1[e], ng = s2[e], hn = s3[e];
+                            const float dht = g + carry[i][k][e];
+                            const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
+                            da[0][r] = dan * hn * rg * (1.0f - rg);
+                            da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
+                            da[2][r] = dan;
+                            da[3][r] = dan * rg;
+                            carry[i][k][e] = dht * zg;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                bf16x8 a, b;
+                for (int gi = 0; gi < 4; ++gi) {
+                    bf16x8 a;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { a[j] = (__bf16)da[gi][j]; b[j] = (__bf16)da[gi][8 + j]; }
-                bf16x8 *fp = (bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-                fp[0] = a;
-                fp[64] = b;
-                if constexpr (!WIDE) {
-                    bf16x8 *lp = (bf16x8 *)(dab + ((size_t)gi * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-                    lp[0] = a;
-                    lp[64] = b;
-                }
-                __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
+                    for (int j = 0; j < 8; ++j) a[j] = (__bf16)da[gi][j];
+                    if constexpr (!WIDE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int unit = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    pl[(size_t)unit * cols] = r < 8 ? a[r] : b[r - 8];
+                        for (int j = 0; j < 8; ++j) dbacc[gi][8 * half + j] += da[gi][j];
+                    }
+                    *((bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
+                    if constexpr (!WIDE) *((bf16x8 *)(dab + ((size_t)gi * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
+                    __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int unit = 32 * u + (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * hf;
+                        pl[(size_t)unit * cols] = a[j];
+                    }
                 }
             }
         }
@@ -562,12 +652,24 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                 for (int term = 0; term < q.nterm; ++term) {
                     const bf16x8 *bp = (const bf16x8 *)(dab + (size_t)q.slab[term] * p.kh * TD_FRAG_BYTES) + lane;
                     const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
-#pragma unroll 16
+#pragma unroll 8
                     for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dh[i][r >> 2][r & 3] = acc[r];
             }
+        }
+    }
+    if constexpr (!WIDE) {
+        if (w < p.nu) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = td_half_wave_sum(dbacc[gi][r]);
+                    const int unit = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    if (m == 0 && unit < p.H) td_bias_add(p.db_ih[d], p.db_hh[d], p.gru, p.H, gi, unit, t);
+                }
         }
     }
 }
@@ -675,30 +777,32 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
         p.act = ws + t.act[N - 1];
         p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.film = film; p.gy = grad_y;
         p.gout = ws + t.gout[N - 1][0];
+        p.chan = (float *)(ws + t.chan); p.g1 = (float *)(ws + t.g1);
         p.d_film = grad_film; p.d_ln_w = grad_misc[TD_LN_W]; p.d_ln_b = grad_misc[TD_LN_B];
         p.d_fc_w = grad_misc[TD_FC_W]; p.d_fc_b = grad_misc[TD_FC_B];
         TD_REQUIRE(p.d_ln_w && p.d_ln_b && p.d_fc_w && p.d_fc_b, "NULL gradient pointer for the head parameters");
         p.B = batch; p.L = L; p.nbb = t.nbb; p.H = H; p.hpad = g.hpad; p.kh = g.kh; p.dirs = D; p.c_out = cfg->c_out;
         const size_t ntask = (size_t)L * t.nbb;
         int blocks = (int)((ntask + 3) / 4);
-        if (blocks > 1024) blocks = 1024;
+        if (blocks > 2048) blocks = 2048;
         const int DHP = D * g.hpad;
         const size_t lds_max = 160 * 1024;
         auto launch = [&](auto kern, size_t shm) -> int {
-            TD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            if (shm) TD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, stream, p);
             TD_LAUNCH_CHECK();
             return TD_OK;
         };
         const int cm = cfg->c_out <= 16 ? 16 : 32;
-        const size_t shm_full = ((size_t)(4 + 2 * cm) * DHP + cm) * sizeof(float), shm_acc = ((size_t)(2 + cm) * DHP + cm) * sizeof(float);
-        if (shm_full <= lds_max) rc = cm == 16 ? launch(td_head_bwd_kernel<16, false>, shm_full) : launch(td_head_bwd_kernel<32, false>, shm_full);
-        else if (shm_acc <= lds_max) rc = cm == 16 ? launch(td_head_bwd_kernel<16, true>, shm_acc) : launch(td_head_bwd_kernel<32, true>, shm_acc);
-        else {
-            td_set_error("training with c_out = %d > 16 and dirs * hidden = %d > 1024 is not supported by this build", cfg->c_out, DH);
-            return TD_ERR_UNSUPPORTED;
-        }
+        const size_t shm = (size_t)(1 + cm) * DHP * sizeof(float);
+        if (shm <= lds_max) rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, false>, shm) : launch(td_head_bwd_dh_kernel<32, false>, shm);
+        else rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, true>, 0) : launch(td_head_bwd_dh_kernel<32, true>, 0);
         if (rc != TD_OK) return rc;
+        const int rows = batch * cfg->c_out;
+        hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, stream, grad_y, p.g1, rows, L);
+        TD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16)), dim3(256), 0, stream, p);
+        TD_LAUNCH_CHECK();
     }
     if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
 
@@ -715,7 +819,12 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
             p.save = (const float *)(ws + t.save[l]); p.save_dir = t.save_dir_floats;
             p.daf = ws + t.daf[l][0]; p.daf_dir = D > 1 ? t.daf[l][1] - t.daf[l][0] : 0;
             p.dapl = (__bf16 *)(ws + t.dapl[l][0]); p.dapl_dir = D > 1 ? (t.dapl[l][1] - t.dapl[l][0]) / 2 : 0;
-            p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru;
+            p.L = L; p.nbb = t.nbb; p.nu = g.nu; p.kh = g.kh; p.dirs = D; p.out_frags = KT; p.gru = cfg->gru; p.H = H;
+            for (int d = 0; d < 2; ++d) {
+                float *const *gw = grad_layer + (size_t)(l * D + (d < D ? d : 0)) * 4;
+                TD_REQUIRE(gw[2] && gw[3], "NULL bias gradient pointer for layer %d dir %d", l, d);
+                p.db_ih[d] = gw[2]; p.db_hh[d] = gw[3];
+            }
             q.wt = wT; q.wt_dir = packT_dir; q.nterm = G;
             q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
             const int mode = td_layer_kernel_mode();
@@ -725,7 +834,8 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                 cp.save = p.save; cp.save_dir = p.save_dir; cp.daf = p.daf; cp.daf_dir = p.daf_dir;
                 cp.dapl = p.dapl; cp.dapl_dir = p.dapl_dir; cp.wt = wT; cp.wt_dir = packT_dir;
                 cp.inbox = (unsigned long long *)(ws + t.inbox);
-                cp.L = L; cp.nbb = t.nbb; cp.dirs = D; cp.out_frags = KT;
+                cp.L = L; cp.nbb = t.nbb; cp.dirs = D; cp.out_frags = KT; cp.H = H;
+                for (int d = 0; d < 2; ++d) { cp.db_ih[d] = p.db_ih[d]; cp.db_hh[d] = p.db_hh[d]; }
                 rc = td_launch_bptt_cluster(cfg->gru, g, cp, stream);
                 if (rc != TD_OK) return rc;
             } else if (g.nu <= 8) {
@@ -784,7 +894,8 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                     rc = td_dw_gemm(q, GM * g.nu, stream);
                     if (rc != TD_OK) return rc;
                 }
-                // biases
+                // biases (hidden sizes up to 256: folded into the sweep)
+                if (g.nu <= 8) continue;
                 hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(GM * H, 4)), dim3(256), 0, stream,
                                    dapl + (size_t)slab_x * t.dapl_slab_elems, t.cols, GM * H, t.cols, gw[2] + gate * H,
                                    slab_h == slab_x ? gw[3] + gate * H : (float *)nullptr);
