@@ -11,8 +11,11 @@ static rocblas_handle g_blas = nullptr;
 // C[m][n] += sum_k A[m][k] B[n][k]; A, B row-major bf16 with k contiguous (lda, ldb), C row-major fp32 (ldc).
 // One path per shape: the caller (td_dw_gemm, rnn_train.hip) decides from the shape alone whether this runs; a failure
 // here is an error, never a silent switch to another kernel.
+// nsplit > 1: the contraction index is cut into nsplit equal chunks that run as the batches of ONE strided-batched GEMM,
+// each writing its own M x N partial result (row-major, packed) into `partial`; the caller adds them to C.  With K in
+// the hundreds of thousands and M x N of only a few 256 x 256 tiles this is what fills the chip.
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
-                   hipStream_t stream) {
+                   int nsplit, float *partial, hipStream_t stream) {
     if (!g_blas) {
         if (rocblas_create_handle(&g_blas) != rocblas_status_success) {
             g_blas = nullptr;
@@ -24,7 +27,20 @@ int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *
         td_set_error("rocblas_set_stream failed");
         return TD_ERR_HIP;
     }
-    const float one = 1.0f;
+    const float one = 1.0f, zero = 0.0f;
+    if (nsplit > 1) {
+        const int kc = K / nsplit;
+        rocblas_status st = rocblas_gemm_strided_batched_ex(
+            g_blas, rocblas_operation_transpose, rocblas_operation_none, N, M, kc, &one, B, rocblas_datatype_bf16_r, (rocblas_int)ldb,
+            (rocblas_stride)kc, A, rocblas_datatype_bf16_r, (rocblas_int)lda, (rocblas_stride)kc, &zero, partial, rocblas_datatype_f32_r, N,
+            (rocblas_stride)M * N, partial, rocblas_datatype_f32_r, N, (rocblas_stride)M * N, nsplit, rocblas_datatype_f32_r,
+            rocblas_gemm_algo_standard, 0, 0);
+        if (st != rocblas_status_success) {
+            td_set_error("rocblas_gemm_strided_batched_ex failed with status %d (M=%d N=%d K=%d x %d)", (int)st, M, N, kc, nsplit);
+            return TD_ERR_HIP;
+        }
+        return TD_OK;
+    }
     // column-major view: C' (N x M, ld ldc) = Bc^T (N x K) . Ac (K x M), Bc = B as (K x N, ld ldb), Ac = A as (K x M, ld lda)
     rocblas_status st = rocblas_gemm_ex(g_blas, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, B,
                                         rocblas_datatype_bf16_r, (rocblas_int)ldb, A, rocblas_datatype_bf16_r,

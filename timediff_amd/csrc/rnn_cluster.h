@@ -12,6 +12,19 @@ __device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsi
     return ((unsigned long long)tag << 32) | payload;
 }
 
+// Workgroup -> (cluster, member).  Workgroups go to the 8 XCDs round-robin by their index, so the natural order
+// (member = index % NU) would spread a cluster over all XCDs.  This map puts the NU members of a cluster on ONE XCD:
+// index = cluster % 8 + 8 * member + 8 * NU * (cluster / 8), in a grid rounded up to whole groups of 8 clusters whose
+// surplus workgroups leave at once.  Speed only (the hand-off is agent-scope either way): measured against the natural
+// order, 3-layer forward at 32 / 512 / 2048 sequences 2.29 / 3.74 / 13.97 -> 2.20 / 3.15 / 12.94 ms.
+__device__ __forceinline__ bool tdc_block_map(int block, int nclusters, int nu, int *cluster, int *member) {
+    const int span = 8 * nu;
+    *cluster = 8 * (block / span) + block % 8;
+    *member = (block % span) / 8;
+    return *cluster < nclusters;
+}
+static inline int tdc_grid(int nclusters, int nu) { return 8 * nu * ((nclusters + 7) / 8); }
+
 unsigned td_cluster_next_epoch(void);   // rnn_cluster.hip: one counter for every cluster launch of the process (20 bits)
 
 // ---- BPTT sweep of one layer by the cluster (rnn_cluster_bwd.hip) ------------------------------------------------------

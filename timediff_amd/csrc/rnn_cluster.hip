@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = blockIdx.x % NU, grp = blockIdx.x / NU;
+    int c, grp;
+    if (!tdc_block_map(blockIdx.x, p.dirs * p.ngroups, NU, &grp, &c)) return;
     const int dir = grp % p.dirs, gi = grp / p.dirs;
     const int nblk = (p.nbb - gi + p.ngroups - 1) / p.ngroups;   // batch blocks of this cluster (>= 1)
 
@@ -343,7 +344,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = blockIdx.x % NU, grp = blockIdx.x / NU;
+    int c, grp;
+    if (!tdc_block_map(blockIdx.x, p.dirs * p.ngroups, NU, &grp, &c)) return;
     const int dir = grp % p.dirs, gi = grp / p.dirs;
     const int nblk = (p.nbb - gi + p.ngroups - 1) / p.ngroups;
 
@@ -523,7 +525,7 @@ int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayer
     const int max_groups = TDC_CUS / (g.nu * lp.dirs);
     p.ngroups = lp.nbb < max_groups ? lp.nbb : max_groups;
     p.epoch = td_cluster_next_epoch();
-    const int blocks = g.nu * lp.dirs * p.ngroups;
+    const int blocks = tdc_grid(lp.dirs * p.ngroups, g.nu);
     if (g.nu != 8) {
         td_set_error("cluster kernel: hidden block count %d is not instantiated", g.nu);
         return TD_ERR_UNSUPPORTED;

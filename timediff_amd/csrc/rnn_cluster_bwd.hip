@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hf = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = blockIdx.x % NU, grp = blockIdx.x / NU;
+    int c, grp;
+    if (!tdc_block_map(blockIdx.x, p.dirs * p.nbb, NU, &grp, &c)) return;
     const int dir = grp % p.dirs, bb = grp / p.dirs;
 
     // ---- this workgroup's slice of W_hh^T: rows = every hidden unit (the wave's two row blocks), k = its own 32 units
@@ -250,7 +251,7 @@ int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, h
         return TD_ERR_UNSUPPORTED;
     }
     p.epoch = td_cluster_next_epoch();
-    const int blocks = g.nu * p.dirs * p.nbb;
+    const int blocks = tdc_grid(p.dirs * p.nbb, g.nu);
     if (gru) hipLaunchKernelGGL((td_bptt_cluster_kernel<8, true>), dim3(blocks), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((td_bptt_cluster_kernel<8, false>), dim3(blocks), dim3(256), 0, stream, p);
     TD_LAUNCH_CHECK();

@@ -24,18 +24,31 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
                          char *const *acts, float *const *saves, float *state, hipStream_t stream);
 // gemm_lib.cpp (rocBLAS)
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
-                   hipStream_t stream);
+                   int nsplit, float *partial, hipStream_t stream);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
                 const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// split-K of the library weight-gradient GEMMs: chunks of at least TD_DW_SPLIT_MIN_K columns, partial results within
+// TD_DW_PARTIAL_BYTES, until (256 x 256 tiles) x chunks reaches the CU count
+#define TD_DW_SPLIT_MIN_K 8192
+#define TD_DW_PARTIAL_BYTES ((size_t)64 << 20)
+static int td_dw_nsplit(int M, int N, int K) {
+    const int tiles = td_cdiv(M, 256) * td_cdiv(N, 256);
+    int ns = 1;
+    while (ns < 64 && tiles * ns < 256 && K % (16 * ns) == 0 && K / (2 * ns) >= TD_DW_SPLIT_MIN_K &&
+           (size_t)M * N * sizeof(float) * (2 * ns) <= TD_DW_PARTIAL_BYTES)
+        ns *= 2;
+    return ns;
+}
 
 // ---------------------------------------------------------------------------------------------
 // training workspace
 // ---------------------------------------------------------------------------------------------
 struct TdTrainLayout {
     int nbb, Bp, cpad;      // batch blocks, padded batch, layer-0 channels padded to 32
-    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, total;
+    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, dwpart, total;
     size_t act_bytes, save_dir_floats, daf_bytes, dapl_slab_elems, cols;
 };
 
@@ -70,7 +83,8 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
     }
     t.chan = take((size_t)L * t.nbb * (cfg->c_out + 1) * 32 * sizeof(float));   // head backward: g * rstd per channel, mu
     t.g1 = take((size_t)batch * cfg->c_out * sizeof(float));
-    t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));   // the cluster BPTT sweep's partial-sum exchange (small batches only)
+    t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));
+    t.dwpart = take(t.cols >= 2 * TD_DW_SPLIT_MIN_K ? TD_DW_PARTIAL_BYTES : 0);   // split-K partial results of the weight-gradient GEMMs   // the cluster BPTT sweep's partial-sum exchange (small batches only)
     t.total = off;
     return t;
 }
@@ -243,6 +257,7 @@ struct TdHeadBwdParams {
     float *g1;                                    // [B][c_out]: sum over l of grad_y
     float *d_film, *d_ln_w, *d_ln_b, *d_fc_w, *d_fc_b;  // accumulated (atomics)
     int B, L, nbb, H, hpad, kh, dirs, c_out;
+    int lch, llen;                                // parameter kernel: the steps are cut into lch chunks of llen
 };
 
 // sum over the 32 lanes that share bit 5 of the lane id (one half-wave = the 32 sequences of a batch block)
@@ -378,13 +393,16 @@ __global__ __launch_bounds__(256) void td_rowsum_kernel(const float *__restrict_
     if (lane == 0) out[row] = s;
 }
 
-// wave = (batch block blockIdx.x, fragment blockIdx.y * 4 + wave, channels [NC * blockIdx.z, + NC))
+// wave = (batch block blockIdx.x, fragment blockIdx.y * 4 + wave, channels [NC * (blockIdx.z / lch), + NC), steps of chunk
+// blockIdx.z % lch): small batches are cut along the steps so that the launch still has a few thousand waves; every result
+// is accumulated with atomics, and the terms in G1 (whole-sequence sums) are added by chunk 0 alone
 template <int NC>
 __global__ __launch_bounds__(256, 2) void td_head_bwd_param_kernel(TdHeadBwdParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
     const int KT = p.dirs * p.kh, CH = p.c_out + 1, DH = p.dirs * p.H;
-    const int bblk = blockIdx.x, ks = blockIdx.y * 4 + wave, c0 = blockIdx.z * NC;
+    const int bblk = blockIdx.x, ks = blockIdx.y * 4 + wave, c0 = (blockIdx.z / p.lch) * NC, lc = blockIdx.z % p.lch;
     if (ks >= KT) return;
+    const int l0 = lc * p.llen, l1 = min(p.L, l0 + p.llen);
     const int b = bblk * 32 + m;
     const bool valid = b < p.B;
     float X[NC][8];
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void td_head_bwd_param_kernel(TdHeadBwdPara
 #pragma unroll
     for (int c = 0; c < NC; ++c) coff[c] = (c0 + c < p.c_out ? c0 + c : p.c_out - 1) * 32;
 #pragma unroll 2
-    for (int l = 0; l < p.L; ++l) {
+    for (int l = l0; l < l1; ++l) {
         const bf16x8 v = fp[(size_t)l * fstep];
         const float *cl = cp + (size_t)l * cstep;
         const float mu = cl[p.c_out * 32];
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void td_head_bwd_param_kernel(TdHeadBwdPara
     }
     float G1[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) G1[c] = (valid && c0 + c < p.c_out) ? p.g1[(size_t)b * p.c_out + c0 + c] : 0.f;
+    for (int c = 0; c < NC; ++c) G1[c] = (valid && lc == 0 && c0 + c < p.c_out) ? p.g1[(size_t)b * p.c_out + c0 + c] : 0.f;
     const float *film = p.film + (size_t)(valid ? b : 0) * 2 * DH;
     float *dfilm = p.d_film + (size_t)(valid ? b : 0) * 2 * DH;
     const int d = ks / p.kh;
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void td_head_bwd_param_kernel(TdHeadBwdPara
             atomicAdd(&p.d_ln_b[feat], t_lnb);
         }
     }
-    if (ks == 0) {
+    if (ks == 0 && lc == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float t = td_half_wave_sum(G1[c]);
@@ -715,10 +733,28 @@ __global__ __launch_bounds__(256) void td_dw_gemm_kernel(TdDwParams p) {
 // The library GEMM where the shape allows (no column remap: hidden a multiple of 32, not the first layer's padded
 // channels; leading dimensions within rocBLAS's 32-bit range), the kernel above otherwise.  The choice depends on the
 // shape (and the explicit td_set_dw_gemm knob) only: a library failure is returned as an error.
+// C[m][n] += sum over the nsplit partial results (each M x N, packed)
+__global__ __launch_bounds__(256) void td_dw_reduce_kernel(const float *__restrict__ part, float *__restrict__ C, int M, int N, int ldc,
+                                                           int nsplit) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + i];
+        C[(i / N) * ldc + i % N] += s;
+    }
+}
+
 int td_dw_gemm_mode(void);   // api.cpp
-static int td_dw_gemm(const TdDwParams &q, int nu, hipStream_t stream) {
-    if (q.hp == q.hv && td_dw_gemm_mode() != TD_DW_GEMM_KERNEL && q.lda <= 0x7fffffff && q.ldb <= 0x7fffffff)
-        return td_dw_gemm_lib(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, stream);
+static int td_dw_gemm(const TdDwParams &q, int nu, float *partial, hipStream_t stream) {
+    if (q.hp == q.hv && td_dw_gemm_mode() != TD_DW_GEMM_KERNEL && q.lda <= 0x7fffffff && q.ldb <= 0x7fffffff) {
+        const int ns = partial ? td_dw_nsplit(q.M, q.N, q.K) : 1;
+        int rc = td_dw_gemm_lib(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, ns, partial, stream);
+        if (rc != TD_OK || ns == 1) return rc;
+        const size_t total = (size_t)q.M * q.N;
+        hipLaunchKernelGGL(td_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, q.C, q.M, q.N, q.ldc, ns);
+        TD_LAUNCH_CHECK();
+        return TD_OK;
+    }
     hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
     TD_LAUNCH_CHECK();
     return TD_OK;
@@ -801,11 +837,19 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
         const int rows = batch * cfg->c_out;
         hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, stream, grad_y, p.g1, rows, L);
         TD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16)), dim3(256), 0, stream, p);
+        // about 2048 waves per launch, chunks of at least 16 steps
+        p.lch = 2048 / (t.nbb * D * g.kh);
+        if (p.lch > L / 16) p.lch = L / 16;
+        if (p.lch < 1) p.lch = 1;
+        p.llen = td_cdiv(L, p.lch);
+        p.lch = td_cdiv(L, p.llen);
+        hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16) * p.lch), dim3(256), 0,
+                           stream, p);
         TD_LAUNCH_CHECK();
     }
     if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
 
+    float *dwpart = t.cols >= 2 * TD_DW_SPLIT_MIN_K ? (float *)(ws + t.dwpart) : nullptr;
     // ---- layers, top down ------------------------------------------------------------------------
     const int KT = D * g.kh;
     for (int l = N - 1; l >= 0; --l) {
@@ -881,7 +925,7 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                 q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = GM * H; q.K = (int)t.cols;
                 if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
                 else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
-                rc = td_dw_gemm(q, GM * g.nu, stream);
+                rc = td_dw_gemm(q, GM * g.nu, dwpart, stream);
                 if (rc != TD_OK) return rc;
                 // W_hh: h_{t-1} is this direction's own output one step earlier in its processing order
                 if (L > 1) {
@@ -891,7 +935,7 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
                     q.B = d == 0 ? hpl : hpl + t.Bp;
                     q.C = gw[1] + (size_t)gate * H * H; q.ldc = H; q.K = (int)(t.cols - t.Bp);
                     q.N = g.hpad; q.hp = g.hpad; q.hv = H;
-                    rc = td_dw_gemm(q, GM * g.nu, stream);
+                    rc = td_dw_gemm(q, GM * g.nu, dwpart, stream);
                     if (rc != TD_OK) return rc;
                 }
                 // biases (hidden sizes up to 256: folded into the sweep)
