@@ -96,7 +96,7 @@ def cpu_baseline(sd, cols, L, T, tables, seconds_target=15.0):
                        f"{per_step:.2f} s/step, extrapolated to T={T}")
 
 
-def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup):
+def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
     """Second half of BASELINE.json's metric: optimizer steps / second of the ETDiff training loop
     (et_diff.py:226-261: ga micro-batches of MixedDiffusion.forward + backward, clip, Adam, EMA) on synthetic
     eICU-shaped data, through the same module interface the reference's CLI uses."""
@@ -116,7 +116,8 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup):
     for c in cols["cat"]:
         data[:, c] = (data[:, c] > 0.5).float()
     et = ETDiff(diff, TensorSeriesDataset(data, cols["cat"]), train_batch_size=batch, gradient_accumulate_every=ga,
-                diff_lr=8e-5, diff_num_steps=steps, ema_update_every=10, check_point_path="/tmp/bench_ckpt.pt")
+                diff_lr=8e-5, diff_num_steps=steps, ema_update_every=10, check_point_path="/tmp/bench_ckpt.pt",
+                fuse_accumulation=fuse)
     for _ in range(warmup):
         et.train_step()
     torch.cuda.synchronize()
@@ -129,7 +130,8 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup):
     return dict(value=steps / el, unit="optimizer steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
                 config=dict(workload=f"ETDiff eICU-shaped training step: global batch {batch}, grad-accum {ga}, L={L}, "
                                      f"3-layer bidirectional LSTM H={H}, T={T}, Adam + clip + EMA",
-                            batch=batch, gradient_accumulate_every=ga),
+                            batch=batch, gradient_accumulate_every=ga,
+                            accumulation="micro-batches concatenated into one launch" if fuse and ga > 1 else "loop"),
                 sequences_per_s=steps * batch * ga / el, final_loss=float(loss))
 
 
@@ -274,7 +276,8 @@ def main():
             del out, z, idx, mo
             torch.cuda.empty_cache()
             train = {"reference_batch": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 2),
-                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 3, 1)}
+                     "reference_batch_looped": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 2, fuse=False),
+                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 6, 2)}
         fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
         result = {
             "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,

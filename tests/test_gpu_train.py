@@ -18,7 +18,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _build(g, dev, ga, lr, tmp_path, T, L, H, N):
+def _build(g, dev, ga, lr, tmp_path, T, L, H, N, fuse=True):
     from models.ETDiff.blocks import RNN
     from models.ETDiff.et_diff import ETDiff
     from models.ETDiff.mixed_diffusion import MixedDiffusion
@@ -32,19 +32,24 @@ def _build(g, dev, ga, lr, tmp_path, T, L, H, N):
     assert not missing.missing_keys and not missing.unexpected_keys
     ds = TensorSeriesDataset(torch.from_numpy(g["data"].reshape(-1, *g["data"].shape[2:])), cat)
     et = ETDiff(diff, ds, train_batch_size=g["data"].shape[1], gradient_accumulate_every=ga, diff_lr=lr,
-                diff_num_steps=2, ema_update_every=1, check_point_path=str(tmp_path / "ckpt.pt"))
+                diff_num_steps=2, ema_update_every=1, check_point_path=str(tmp_path / "ckpt.pt"), fuse_accumulation=fuse)
     return et
 
 
-def test_train_steps_against_reference(dev, tmp_path):
+@pytest.mark.parametrize("fuse", [False, True])
+def test_train_steps_against_reference(fuse, dev, tmp_path):
+    """Two optimizer steps of the reference loop (gradient_accumulate_every = 2), micro-batch by micro-batch as the
+    reference runs them (fuse = False) and with the micro-batches of a step concatenated into one launch (the default):
+    the same golden losses, gradient norms and weights."""
     g = load_golden("train_steps_eicu")
     L, H, N, T, B, ga = [int(v) for v in g["cfg"]]
     lr = float(g["lr"])
-    et = _build(g, dev, ga, lr, tmp_path, T, L, H, N)
+    et = _build(g, dev, ga, lr, tmp_path, T, L, H, N, fuse)
     # feed the reference's batches and its recorded draws (t, noise, uniforms) in order
     batches = iter([torch.from_numpy(b.copy()) for b in g["data"]])
-    draws = iter([dict(t=torch.from_numpy(g["t"][i]).to(dev), noise=torch.from_numpy(g["noise"][i]).to(dev),
-                       uniforms=torch.from_numpy(g["uniforms"][i]).to(dev)) for i in range(len(g["t"]))])
+    per_call = ga if fuse else 1       # the fused step draws for the concatenated batch
+    draws = iter([{k: torch.cat([torch.from_numpy(g[k][i + j]) for j in range(per_call)]).to(dev) for k in ("t", "noise", "uniforms")}
+                  for i in range(0, len(g["t"]), per_call)])
     et.dl = batches
     inner = et.model.forward
     et.model.forward = lambda sample: inner(sample, **next(draws))
@@ -72,7 +77,7 @@ def test_train_steps_against_reference(dev, tmp_path):
     params = [torch.nn.Parameter(v.clone()) for k, v in ck["diff_model"].items() if k.startswith("model.")]
     torch.optim.Adam(params, lr=lr, betas=(0.9, 0.99)).load_state_dict(ck["opt"])
     # resume: a fresh trainer restores weights, step count and Adam moments
-    et2 = _build(g, dev, ga, lr, tmp_path, T, L, H, N)
+    et2 = _build(g, dev, ga, lr, tmp_path, T, L, H, N, fuse)
     et2.load(et.check_point_path)
     assert et2.step == 2 and et2.opt_step == 2
     assert torch.equal(et2.flat_param, et.flat_param) and torch.equal(et2.exp_avg_sq, et.exp_avg_sq)

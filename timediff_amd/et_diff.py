@@ -104,7 +104,7 @@ class ETDiff(nn.Module):
     def __init__(self, diffusion_model, dataset, *, train_batch_size=16, gradient_accumulate_every=1, diff_lr=1e-4,
                  diff_num_steps=100000, ema_update_every=10, ema_decay=0.995, adam_betas=(0.9, 0.99),
                  sample_every=1000, amp=False, mixed_precision_type="fp16", split_batches=True, wandb=None,
-                 check_point_path="results/checkpoint.pt", run_id=2023):
+                 check_point_path="results/checkpoint.pt", run_id=2023, fuse_accumulation=True):
         super().__init__()
         if amp:
             raise NotImplementedError("amp is hard-wired to False by the reference's CLI (etdiff_train.py:270)")
@@ -137,6 +137,11 @@ class ETDiff(nn.Module):
         self.sample_every = sample_every
         self.batch_size = train_batch_size
         self.gradient_accumulate_every = gradient_accumulate_every
+        # The reference sums the gradients of gradient_accumulate_every micro-batch losses, each divided by that count
+        # (et_diff.py:231-237): with micro-batches of equal size that is the gradient of the mean loss over their
+        # concatenation, so they run as ONE launch (the recurrent kernels at the reference's batch of 32 are bound by
+        # step latency, not throughput: two batch blocks take the time of one).  False restores the loop.
+        self.fuse_accumulation = bool(fuse_accumulation)
         self.diff_num_steps = diff_num_steps
         self.run_id = run_id
 
@@ -309,11 +314,14 @@ class ETDiff(nn.Module):
         """gradient_accumulate_every micro-batches + one optimizer step; -> the step's loss (device scalar)."""
         ga = self.gradient_accumulate_every
         total = torch.zeros((), dtype=torch.float32, device=self.device)
-        for i in range(ga):
+        batches = [next(self.dl) for _ in range(ga)]
+        if self.fuse_accumulation and ga > 1 and all(b.shape[0] == batches[0].shape[0] for b in batches):
+            batches, ga = [torch.cat(batches)], 1       # mean over the concatenation = sum of the micro-batch means / ga
+        for i, data in enumerate(batches):
             if self._sink is not None:
                 overlap = self._dp and self._overlap and i == ga - 1
                 self._sink["on_layer_done"] = self._layer_reduce if overlap else None
-            data = next(self.dl).to(self.device, non_blocking=True)
+            data = data.to(self.device, non_blocking=True)
             loss = self.model(data) / ga
             total += loss.detach()
             loss.backward()

@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--seq-len", type=int, default=272)
+ap.add_argument("--loop", action="store_true", help="gradient accumulation as a loop over micro-batches (the reference's form)")
 a = ap.parse_args()
 torch.cuda.set_device(0)
-print(json.dumps(train_probe(torch.device("cuda", 0), EICU, a.seq_len, a.hidden, 3, 1000, a.batch, a.ga, a.steps, a.warmup)))
+print(json.dumps(train_probe(torch.device("cuda", 0), EICU, a.seq_len, a.hidden, 3, 1000, a.batch, a.ga, a.steps, a.warmup, fuse=not a.loop)))
