@@ -42,9 +42,10 @@ struct TdClusterBwdParams {
     unsigned long long *inbox;   // [dir][bblk][parity][dst c'][src c][wave][lane][2] granules
     float *db_ih[2], *db_hh[2];  // per direction: bias gradients (accumulated): row sums of d a over steps and sequences
     int L, nbb, dirs, out_frags, H;
+    int ngroups;                 // clusters per direction; cluster gi works the batch blocks gi, gi + ngroups, ...
     unsigned epoch;
 };
 
 bool td_bptt_cluster_supported(const TdRnnGeom &g, int nbb, int L);
 size_t td_bptt_cluster_inbox_bytes(const TdRnnGeom &g, int nbb);
-int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, hipStream_t stream);   // sets p.epoch
+int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, hipStream_t stream);   // sets p.epoch, p.ngroups

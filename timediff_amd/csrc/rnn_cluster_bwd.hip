@@ -16,24 +16,50 @@
 //   * d c (LSTM) / z * d h (GRU) carries and the accumulators never leave registers; the saved gate values and the
 //     incoming output gradients of the next step are prefetched under the current step's MFMAs.
 // d a_t leaves in the two layouts the batched GEMMs after the sweep read (fragments for d x = W_ih^T d a, plain rows for
-// d W), exactly as td_bptt_sweep_kernel writes them.  One batch block per cluster: NU * dirs * batch blocks <= 256.
+// d W), exactly as td_bptt_sweep_kernel writes them.
+// Batches beyond one block per cluster (NU * dirs * batch blocks > 256 CUs): a cluster works its blocks one after the
+// other within a step, up to TDC_BWD_MAX_BLOCKS of them; block j's partial sums were sent a whole round of blocks ago,
+// so its granules are fetched one iteration ahead and normally all carry the right tag at the first look; the carries
+// of the blocks live in LDS.
 #include "rnn_cluster.h"
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tdc_bf16x4;
 
-template <int NU, bool GRU>
+// 16-byte write-through store (global_store_dwordx4 sc1): the form the bandwidth hand-off below is built on
+typedef __attribute__((ext_vector_type(4))) unsigned tdc_u32x4;
+// The s_nop covers the hazard of a store of more than 8 bytes whose data registers the next VALU instruction overwrites:
+// the compiler's hazard recognizer does not look inside inline asm (it scheduled a v_mov_dpp into the data registers
+// right behind the store, and the store then wrote the new value).
+__device__ __forceinline__ void tdc_store16_sc1(void *ptr, tdc_u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+// the value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ unsigned tdc_swap1(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+
+// MULTI = the cluster works several batch blocks per step.  Then a block's partial sums are needed a whole round of
+// blocks after they were sent and the hand-off is built for bandwidth instead of latency (at a full chip the tagged
+// 8-byte granules are one fabric write each, 1 M of them per iteration: 7 us): payload without tags, written by 16-byte
+// sc1 stores (two neighbouring lanes' 8 bytes each, exchanged by DPP), one flag word per (destination, source) written by
+// one wave behind the next iteration's workgroup barrier, after every wave's s_waitcnt vmcnt(0); the receiver polls the
+// 8 flags of its block and then reads the payload with 8-byte sc1 loads (MI355X_MICROARCH.md, hand-offs with sc1 loads
+// in place of the acquire, first row).
+template <int NU, bool GRU, bool MULTI>
 __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdParams p) {
     constexpr int KH = 2 * NU, NT = GRU ? 3 : 4;
     constexpr int RBW = NU / TDC_WAVES;                 // row blocks of the partial product per wave
     constexpr size_t PAR = (size_t)NU * NU * TDC_WAVES * 128;   // granules per parity buffer
     static_assert(NU % TDC_WAVES == 0, "row blocks must split over the waves");
-    __shared__ __attribute__((aligned(16))) char lds[2 * 8 * TD_FRAG_BYTES];   // d a_t of the 32 own units: [parity][slab][half]
+    // d a_t of the 32 own units [parity][slab][half] (16 KiB), then the carries of a cluster that works several batch
+    // blocks: [block][thread] f32x4
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    f32x4 *carry_lds = (f32x4 *)(lds + 2 * 8 * TD_FRAG_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hf = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int c, grp;
-    if (!tdc_block_map(blockIdx.x, p.dirs * p.nbb, NU, &grp, &c)) return;
-    const int dir = grp % p.dirs, bb = grp / p.dirs;
+    if (!tdc_block_map(blockIdx.x, p.dirs * p.ngroups, NU, &grp, &c)) return;
+    const int dir = grp % p.dirs, gi0 = grp / p.dirs;
+    const int nblk = (p.nbb - gi0 + p.ngroups - 1) / p.ngroups;   // batch blocks gi0, gi0 + ngroups, ... (>= 1)
 
     // ---- this workgroup's slice of W_hh^T: rows = every hidden unit (the wave's two row blocks), k = its own 32 units
     bf16x8 W[RBW][NT][2];
@@ -47,162 +73,255 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                                                     (((size_t)(RBW * w + rbi) * NT + t) * KH + 2 * c + half) * TD_FRAG_BYTES) + lane);
 
     const unsigned tag0 = p.epoch << 12;
-    unsigned long long *inbox = p.inbox + (size_t)(dir * p.nbb + bb) * 2 * PAR;
     const size_t cols = (size_t)p.L * p.nbb * 32;
     constexpr int hpad = 32 * NU;
     const size_t sub = (size_t)lane * 16 + 8 * (w & 1);     // this wave's 8 bytes of a fragment's lane row
     const int kfrag = 2 * c + (w >> 1);                     // the k-step fragment its 4 units per lane belong to
 
     auto lpos = [&](int s) { return dir ? s : p.L - 1 - s; };            // BPTT step s works forward position l
-    auto save_at = [&](int l) {
+    auto save_at = [&](int l, int bb) {
         return p.save + (size_t)dir * p.save_dir + ((((size_t)l * p.nbb + bb) * NU + c) * 5) * 1024 + lane * 16 + 4 * w;
     };
-    // what step s needs from memory, fetched one step ahead
+    auto inbox_of = [&](int bb) { return p.inbox + (size_t)(dir * p.nbb + bb) * 2 * PAR; };
+    // MULTI: [parity][dst][src] flag words of a block, behind the payload of all blocks and directions
+    auto flags_of = [&](int bb) { return (unsigned *)(p.inbox + (size_t)p.dirs * p.nbb * 2 * PAR) + (size_t)(dir * p.nbb + bb) * 2 * NU * NU; };
+    // the partial sums for this wave's units of (step s, block bb): one load of each granule (re-read below while stale)
+    unsigned long long gr[2 * NU];
+    auto poll_issue = [&](int s, int bb) {
+        const unsigned long long *src = inbox_of(bb) + (size_t)((s - 1) & 1) * PAR + ((size_t)(c * NU) * TDC_WAVES + w) * 128 + lane * 2;
+#pragma unroll
+        for (int n = 0; n < 2 * NU; ++n)
+            gr[n] = __hip_atomic_load(src + (size_t)(n >> 1) * (TDC_WAVES * 128) + (n & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // what an iteration needs from memory, fetched one iteration ahead
     f32x4 sv[5], pv;
     unsigned long long gs[2];
-    auto prefetch = [&](int s) {
+    auto prefetch = [&](int s, int bb) {
         const int l = lpos(s);
-        const float *sp = save_at(l);
+        const float *sp = save_at(l, bb);
 #pragma unroll
         for (int q = 0; q < 5; ++q) sv[q] = *(const f32x4 *)(sp + q * 1024);
         pv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (s + 1 < p.L) pv = *(const f32x4 *)(save_at(dir ? l + 1 : l - 1) + 4 * 1024);   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+        if (s + 1 < p.L) pv = *(const f32x4 *)(save_at(dir ? l + 1 : l - 1, bb) + 4 * 1024);   // c_{t-1} (LSTM) / h_{t-1} (GRU)
         const size_t go = (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + kfrag) * TD_FRAG_BYTES + sub;
         gs[0] = *(const unsigned long long *)(p.gsrc[0] + go);
         gs[1] = p.n_src > 1 ? *(const unsigned long long *)(p.gsrc[1] + go) : 0ull;
     };
-    prefetch(0);
+    prefetch(0, gi0);
 
     f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-    float dbacc[4][4];           // bias gradients: d a summed over the steps per lane, over the 32 sequences at the end
+    if (nblk > 1)
+        for (int j = 0; j < nblk; ++j) carry_lds[j * 256 + tid] = carry;     // own slots only: no barrier needed
+    float dbacc[4][4];           // bias gradients: d a summed over steps and blocks per lane, over the 32 sequences at the end
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dbacc[gi][i] = 0.f;
     bool dead = false;
+    unsigned *pend_flags = nullptr;     // MULTI: flags of the payload sent in the iteration before, raised behind the next barrier
+    unsigned pend_tag = 0;
+    int it = 0;                  // iteration = (step s, block j): the LDS staging alternates with its parity
     for (int s = 0; s < p.L; ++s) {
-        const int l = lpos(s), par = s & 1;
-        // ---- d h_t: gradient from above + the cluster's partial sums of W_hh^T d a_{t+1} ---------------------------------
-        f32x4 dh;
-        {
-            const tdc_bf16x4 a = *(const tdc_bf16x4 *)&gs[0], b = *(const tdc_bf16x4 *)&gs[1];
+        const int l = lpos(s);
+        for (int j = 0; j < nblk; ++j, ++it) {
+            const int bb = gi0 + j * p.ngroups, par = it & 1;
+            unsigned long long *inbox = inbox_of(bb);
+            // ---- d h_t: gradient from above + the cluster's partial sums of W_hh^T d a_{t+1} -----------------------------
+            f32x4 dh;
+            {
+                const tdc_bf16x4 a = *(const tdc_bf16x4 *)&gs[0], b = *(const tdc_bf16x4 *)&gs[1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dh[i] = (float)a[i] + (float)b[i];
-        }
-        if (s > 0) {
-            const unsigned long long *src = inbox + (size_t)((s - 1) & 1) * PAR + ((size_t)(c * NU) * TDC_WAVES + w) * 128 + lane * 2;
-            const unsigned want = tag0 | (unsigned)s;          // partial sums of step s - 1 carry the tag (epoch, s)
-            unsigned long long gr[2 * NU];
-#pragma unroll
-            for (int n = 0; n < 2 * NU; ++n)
-                gr[n] = __hip_atomic_load(src + (size_t)(n >> 1) * (TDC_WAVES * 128) + (n & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;
-            while (!dead) {
-                bool ok = true;
-#pragma unroll
-                for (int n = 0; n < 2 * NU; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
-                if (ok) break;
-                if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int n = 0; n < 2 * NU; ++n)
-                    if ((unsigned)(gr[n] >> 32) != want)
-                        gr[n] = __hip_atomic_load(src + (size_t)(n >> 1) * (TDC_WAVES * 128) + (n & 1), __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 4; ++i) dh[i] = (float)a[i] + (float)b[i];
             }
+            if (s > 0 && !MULTI) {
+                const unsigned long long *src = inbox + (size_t)((s - 1) & 1) * PAR + ((size_t)(c * NU) * TDC_WAVES + w) * 128 + lane * 2;
+                const unsigned want = tag0 | (unsigned)s;          // partial sums of step s - 1 carry the tag (epoch, s)
+                poll_issue(s, bb);
+                int spins = 0;
+                while (!dead) {
+                    bool ok = true;
 #pragma unroll
-            for (int n = 0; n < 2 * NU; ++n) {
-                const unsigned pl = (unsigned)gr[n];
-                dh[2 * (n & 1)] += __builtin_bit_cast(float, pl << 16);
-                dh[2 * (n & 1) + 1] += __builtin_bit_cast(float, pl & 0xffff0000u);
-            }
-        }
-        // ---- gate gradients of this lane's 4 units ------------------------------------------------------------------------
-        float da[4][4];
+                    for (int n = 0; n < 2 * NU; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
+                    if (ok) break;
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float g = dh[i], prev = pv[i];
-            if constexpr (!GRU) {
-                const float ig = sv[0][i], fg = sv[1][i], gg = sv[2][i], og = sv[3][i], cv = sv[4][i];
-                const float tc = td_tanh(cv);
-                const float dcv = carry[i] + g * og * (1.0f - tc * tc);
-                da[0][i] = dcv * gg * ig * (1.0f - ig);
-                da[1][i] = dcv * prev * fg * (1.0f - fg);
-                da[2][i] = dcv * ig * (1.0f - gg * gg);
-                da[3][i] = g * tc * og * (1.0f - og);
-                carry[i] = dcv * fg;
-            } else {
-                const float rg = sv[0][i], zg = sv[1][i], ng = sv[2][i], hn = sv[3][i];
-                const float dht = g + carry[i];
-                const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
-                da[0][i] = dan * hn * rg * (1.0f - rg);
-                da[1][i] = dht * (prev - ng) * zg * (1.0f - zg);
-                da[2][i] = dan;
-                da[3][i] = dan * rg;
-                carry[i] = dht * zg;
+                    for (int n = 0; n < 2 * NU; ++n)
+                        if ((unsigned)(gr[n] >> 32) != want)
+                            gr[n] = __hip_atomic_load(src + (size_t)(n >> 1) * (TDC_WAVES * 128) + (n & 1), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int n = 0; n < 2 * NU; ++n) {
+                    const unsigned pl = (unsigned)gr[n];
+                    dh[2 * (n & 1)] += __builtin_bit_cast(float, pl << 16);
+                    dh[2 * (n & 1) + 1] += __builtin_bit_cast(float, pl & 0xffff0000u);
+                }
             }
-        }
-        if (dead) {
+            if (s > 0 && MULTI) {
+                // the 8 sources' flags of (step s - 1, this block, this workgroup): lanes 0 .. NU - 1 poll one each
+                const unsigned *fl = flags_of(bb) + (size_t)((s - 1) & 1) * NU * NU + c * NU + (lane & (NU - 1));
+                const unsigned want = tag0 | (unsigned)s;
+                int spins = 0;
+                while (!dead) {
+                    const unsigned f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_ballot_w64(f != want) == 0) break;
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");      // the payload loads stay behind the poll
+                // payload [parity][dst][src][wave][lane] x 8 bytes (4 bf16): this lane's 4 units from every source
+                const unsigned long long *src = inbox + (size_t)((s - 1) & 1) * (PAR / 2) + ((size_t)(c * NU) * TDC_WAVES + w) * 64 + lane;
+                unsigned long long pay[NU];
+#pragma unroll
+                for (int n = 0; n < NU; ++n)
+                    pay[n] = __hip_atomic_load(src + (size_t)n * (TDC_WAVES * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int n = 0; n < NU; ++n) {
+                    const unsigned lo = (unsigned)pay[n], hi = (unsigned)(pay[n] >> 32);
+                    dh[0] += __builtin_bit_cast(float, lo << 16);
+                    dh[1] += __builtin_bit_cast(float, lo & 0xffff0000u);
+                    dh[2] += __builtin_bit_cast(float, hi << 16);
+                    dh[3] += __builtin_bit_cast(float, hi & 0xffff0000u);
+                }
+            }
+            if (nblk > 1) carry = carry_lds[j * 256 + tid];
+            // ---- gate gradients of this lane's 4 units --------------------------------------------------------------------
+            float da[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g = dh[i], prev = pv[i];
+                if constexpr (!GRU) {
+                    const float ig = sv[0][i], fg = sv[1][i], gg = sv[2][i], og = sv[3][i], cv = sv[4][i];
+                    const float tc = td_tanh(cv);
+                    const float dcv = carry[i] + g * og * (1.0f - tc * tc);
+                    da[0][i] = dcv * gg * ig * (1.0f - ig);
+                    da[1][i] = dcv * prev * fg * (1.0f - fg);
+                    da[2][i] = dcv * ig * (1.0f - gg * gg);
+                    da[3][i] = g * tc * og * (1.0f - og);
+                    carry[i] = dcv * fg;
+                } else {
+                    const float rg = sv[0][i], zg = sv[1][i], ng = sv[2][i], hn = sv[3][i];
+                    const float dht = g + carry[i];
+                    const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
+                    da[0][i] = dan * hn * rg * (1.0f - rg);
+                    da[1][i] = dht * (prev - ng) * zg * (1.0f - zg);
+                    da[2][i] = dan;
+                    da[3][i] = dan * rg;
+                    carry[i] = dht * zg;
+                }
+            }
+            if (nblk > 1) carry_lds[j * 256 + tid] = carry;
+            if (dead) {
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) da[gi][i] = __builtin_nanf("");
+            }
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) da[gi][i] = __builtin_nanf("");
-        }
+                for (int i = 0; i < 4; ++i) dbacc[gi][i] += da[gi][i];
+            // MULTI: every vector-memory operation of this wave so far has completed, the payload stores of the iteration before
+            // among them (nothing younger than the loads just consumed is in flight: the wait is free)
+            if constexpr (MULTI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- d a_t: to LDS for the cluster's product, to HBM for the batched GEMMs after the sweep ---------------------------
+            {
+                char *fbase = p.daf + (size_t)dir * p.daf_dir + (((size_t)l * p.nbb + bb) * 4 * KH + kfrag) * TD_FRAG_BYTES + sub;
+                __bf16 *pl = p.dapl + (size_t)dir * p.dapl_dir + (size_t)(32 * c + 8 * w + 4 * hf) * cols + (size_t)l * p.nbb * 32 + bb * 32 + m;
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dbacc[gi][i] += da[gi][i];
-        // ---- d a_t: to LDS for the cluster's product, to HBM for the batched GEMMs after the sweep -----------------------------
-        {
-            char *fbase = p.daf + (size_t)dir * p.daf_dir + (((size_t)l * p.nbb + bb) * 4 * KH + kfrag) * TD_FRAG_BYTES + sub;
-            __bf16 *pl = p.dapl + (size_t)dir * p.dapl_dir + (size_t)(32 * c + 8 * w + 4 * hf) * cols + (size_t)l * p.nbb * 32 + bb * 32 + m;
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                const tdc_bf16x4 v = {(__bf16)da[gi][0], (__bf16)da[gi][1], (__bf16)da[gi][2], (__bf16)da[gi][3]};
-                const unsigned long long bits = *(const unsigned long long *)&v;
-                *(unsigned long long *)(lds + (size_t)(par * 8 + gi * 2 + (w >> 1)) * TD_FRAG_BYTES + sub) = bits;
-                *(unsigned long long *)(fbase + (size_t)gi * KH * TD_FRAG_BYTES) = bits;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pl[((size_t)gi * hpad + i) * cols] = v[i];
-            }
-        }
-        __syncthreads();     // d a_t of the 32 units is in LDS (the other parity is free again two steps on)
-        if (s + 1 >= p.L) break;
-        prefetch(s + 1);
-        // ---- partial sums of W_hh^T d a_t over this workgroup's 32 units, for every hidden unit ----------------------------------
-        bf16x8 B[4][2];
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-                B[gi][half] = *((const bf16x8 *)(lds + (size_t)(par * 8 + gi * 2 + half) * TD_FRAG_BYTES) + lane);
-        f32x16 acc[RBW];
-#pragma unroll
-        for (int rbi = 0; rbi < RBW; ++rbi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rbi][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int slab = GRU ? (t == 2 ? 3 : t) : t;     // GRU: W_hn multiplies r * d a_n
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int rbi = 0; rbi < RBW; ++rbi)
-                    acc[rbi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[rbi][t][half], B[slab][half], acc[rbi], 0, 0, 0);
-        }
-        // ---- send: accumulator registers 4w' .. 4w' + 3 of row block rb belong to wave w' of workgroup rb, same lane -------------
-        {
-            const unsigned tag = tag0 | (unsigned)(s + 1);
-#pragma unroll
-            for (int rbi = 0; rbi < RBW; ++rbi) {
-                unsigned long long *dst = inbox + (size_t)par * PAR + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 128 + lane * 2;
-#pragma unroll
-                for (int wp = 0; wp < TDC_WAVES; ++wp) {
-                    const tdc_bf16x4 v = {(__bf16)acc[rbi][4 * wp], (__bf16)acc[rbi][4 * wp + 1], (__bf16)acc[rbi][4 * wp + 2],
-                                          (__bf16)acc[rbi][4 * wp + 3]};
+                for (int gi = 0; gi < 4; ++gi) {
+                    const tdc_bf16x4 v = {(__bf16)da[gi][0], (__bf16)da[gi][1], (__bf16)da[gi][2], (__bf16)da[gi][3]};
                     const unsigned long long bits = *(const unsigned long long *)&v;
-                    __hip_atomic_store(dst + wp * 128, tdc_granule((unsigned)bits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + wp * 128 + 1, tdc_granule((unsigned)(bits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(unsigned long long *)(lds + (size_t)(par * 8 + gi * 2 + (w >> 1)) * TD_FRAG_BYTES + sub) = bits;
+                    *(unsigned long long *)(fbase + (size_t)gi * KH * TD_FRAG_BYTES) = bits;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pl[((size_t)gi * hpad + i) * cols] = v[i];
+                }
+            }
+            __syncthreads();     // d a_t of the 32 units is in LDS (the other parity is free again two iterations on)
+            if constexpr (MULTI) {
+                // behind the barrier every wave's payload stores of the iteration before are complete: raise its flags
+                if (w == 0 && lane < NU && pend_tag) __hip_atomic_store(pend_flags + lane * NU + c, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend_tag = 0;
+            }
+            // ---- the next iteration's operands: in flight under this one's MFMAs --------------------------------------------------
+            const bool last_blk = j + 1 == nblk;
+            const int s2 = last_blk ? s + 1 : s, bb2 = last_blk ? gi0 : bb + p.ngroups;
+            if (s2 < p.L) prefetch(s2, bb2);
+            if (s + 1 >= p.L) continue;
+            // ---- partial sums of W_hh^T d a_t over this workgroup's 32 units, for every hidden unit ------------------------------
+            bf16x8 B[4][2];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                    B[gi][half] = *((const bf16x8 *)(lds + (size_t)(par * 8 + gi * 2 + half) * TD_FRAG_BYTES) + lane);
+            f32x16 acc[RBW];
+#pragma unroll
+            for (int rbi = 0; rbi < RBW; ++rbi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rbi][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int slab = GRU ? (t == 2 ? 3 : t) : t;     // GRU: W_hn multiplies r * d a_n
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int rbi = 0; rbi < RBW; ++rbi)
+                        acc[rbi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[rbi][t][half], B[slab][half], acc[rbi], 0, 0, 0);
+            }
+            // ---- send: accumulator registers 4w' .. 4w' + 3 of row block rb belong to wave w' of workgroup rb, same lane ---------
+            if constexpr (!MULTI) {
+                const unsigned tag = tag0 | (unsigned)(s + 1);
+#pragma unroll
+                for (int rbi = 0; rbi < RBW; ++rbi) {
+                    unsigned long long *dst = inbox + (size_t)(s & 1) * PAR + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 128 + lane * 2;
+#pragma unroll
+                    for (int wp = 0; wp < TDC_WAVES; ++wp) {
+                        const tdc_bf16x4 v = {(__bf16)acc[rbi][4 * wp], (__bf16)acc[rbi][4 * wp + 1], (__bf16)acc[rbi][4 * wp + 2],
+                                              (__bf16)acc[rbi][4 * wp + 3]};
+                        const unsigned long long bits = *(const unsigned long long *)&v;
+                        __hip_atomic_store(dst + wp * 128, tdc_granule((unsigned)bits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + wp * 128 + 1, tdc_granule((unsigned)(bits >> 32), tag), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                const bool odd = lane & 1;
+#pragma unroll
+                for (int rbi = 0; rbi < RBW; ++rbi) {
+                    // [parity][dst][src][wave w'][lane] x 8 bytes; a lane pair writes 16 bytes: the even lane those of wave w' = 2q,
+                    // the odd lane those of w' = 2q + 1 (each gets the other's 8 bytes for that wave by DPP)
+                    char *dst = (char *)(inbox + (size_t)(s & 1) * (PAR / 2) + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 64) +
+                                (size_t)(lane & ~1) * 8;
+                    unsigned pc[TDC_WAVES][2];
+#pragma unroll
+                    for (int wp = 0; wp < TDC_WAVES; ++wp) {
+                        const tdc_bf16x4 v = {(__bf16)acc[rbi][4 * wp], (__bf16)acc[rbi][4 * wp + 1], (__bf16)acc[rbi][4 * wp + 2],
+                                              (__bf16)acc[rbi][4 * wp + 3]};
+                        const unsigned long long bits = *(const unsigned long long *)&v;
+                        pc[wp][0] = (unsigned)bits;
+                        pc[wp][1] = (unsigned)(bits >> 32);
+                    }
+#pragma unroll
+                    for (int q = 0; q < TDC_WAVES / 2; ++q) {
+                        const unsigned g0 = tdc_swap1(odd ? pc[2 * q][0] : pc[2 * q + 1][0]);    // what the neighbour needs of mine
+                        const unsigned g1 = tdc_swap1(odd ? pc[2 * q][1] : pc[2 * q + 1][1]);
+                        const tdc_u32x4 v = odd ? tdc_u32x4{g0, g1, pc[2 * q + 1][0], pc[2 * q + 1][1]}
+                                                : tdc_u32x4{pc[2 * q][0], pc[2 * q][1], g0, g1};
+                        tdc_store16_sc1(dst + (size_t)(2 * q + (odd ? 1 : 0)) * 512, v);
+                    }
+                }
+                pend_flags = flags_of(bb) + (size_t)(s & 1) * NU * NU;
+                pend_tag = tag0 | (unsigned)(s + 1);
+                if (nblk == 1) {
+                    // a cluster of this launch that has ONE block (the batch blocks do not divide evenly): its next iteration
+                    // is the consumer of these very sums, so the flags cannot wait for that iteration's barrier
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (w == 0 && lane < NU) __hip_atomic_store(pend_flags + lane * NU + c, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend_tag = 0;
                 }
             }
         }
@@ -233,15 +352,31 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// one batch block per cluster, every workgroup resident at once
+#define TDC_BWD_MAX_BLOCKS 16     // batch blocks per cluster (their carries live in LDS: 4 KiB each)
+
+static int tdc_bwd_groups(const TdRnnGeom &g, int nbb) {
+    const int max_groups = TDC_CUS / (g.nu * g.dirs);      // every workgroup resident at once, one per CU
+    return nbb < max_groups ? nbb : max_groups;
+}
+
 bool td_bptt_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
-    return g.nu == TD_CLUSTER_NU && L >= 4 && L < 4096 && nbb >= 1 && g.nu * g.dirs * nbb <= TDC_CUS;
+    if (!(g.nu == TD_CLUSTER_NU && L >= 4 && L < 4096 && nbb >= 1)) return false;
+    return td_cdiv(nbb, tdc_bwd_groups(g, nbb)) <= TDC_BWD_MAX_BLOCKS;
 }
 
 // inbox bytes for a whole layer launch (both directions); 0 where the kernel cannot run
 size_t td_bptt_cluster_inbox_bytes(const TdRnnGeom &g, int nbb) {
-    if (g.nu != TD_CLUSTER_NU || g.nu * g.dirs * nbb > TDC_CUS) return 0;
-    return (size_t)g.dirs * nbb * 2 * g.nu * g.nu * TDC_WAVES * 128 * sizeof(unsigned long long);
+    if (g.nu != TD_CLUSTER_NU || td_cdiv(nbb, tdc_bwd_groups(g, nbb)) > TDC_BWD_MAX_BLOCKS) return 0;
+    // per (direction, block): 2 parities of granules (or of untagged payload, half the size), then 2 x NU x NU flag words
+    return (size_t)g.dirs * nbb * 2 * g.nu * g.nu * (TDC_WAVES * 128 * sizeof(unsigned long long) + sizeof(unsigned));
+}
+
+template <bool GRU, bool MULTI>
+static int tdc_bwd_launch(const TdClusterBwdParams &p, int blocks, size_t shm, hipStream_t stream) {
+    TD_HIP(hipFuncSetAttribute((const void *)td_bptt_cluster_kernel<8, GRU, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((td_bptt_cluster_kernel<8, GRU, MULTI>), dim3(blocks), dim3(256), shm, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
 }
 
 int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, hipStream_t stream) {
@@ -250,10 +385,11 @@ int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, h
                      p.nbb, p.L);
         return TD_ERR_UNSUPPORTED;
     }
+    p.ngroups = tdc_bwd_groups(g, p.nbb);
     p.epoch = td_cluster_next_epoch();
-    const int blocks = tdc_grid(p.dirs * p.nbb, g.nu);
-    if (gru) hipLaunchKernelGGL((td_bptt_cluster_kernel<8, true>), dim3(blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((td_bptt_cluster_kernel<8, false>), dim3(blocks), dim3(256), 0, stream, p);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+    const int blocks = tdc_grid(p.dirs * p.ngroups, g.nu);
+    const int nblk = td_cdiv(p.nbb, p.ngroups);
+    const size_t shm = 2 * 8 * TD_FRAG_BYTES + (nblk > 1 ? (size_t)nblk * 256 * 16 : 0);
+    if (nblk > 1) return gru ? tdc_bwd_launch<true, true>(p, blocks, shm, stream) : tdc_bwd_launch<false, true>(p, blocks, shm, stream);
+    return gru ? tdc_bwd_launch<true, false>(p, blocks, shm, stream) : tdc_bwd_launch<false, false>(p, blocks, shm, stream);
 }
