@@ -225,14 +225,14 @@ def test_cluster_several_blocks_per_cluster(gru, dirs, B, dev, knob):
 
 
 def test_cluster_dispatch_and_agreement(dev, knob):
-    """AUTO takes the cluster kernel where it can run (hidden 193..256, at most 512 sequences bidirectional, at least 4
+    """AUTO takes the cluster kernel where it can run (hidden 193..256, at most 2048 sequences bidirectional, at least 4
     steps) and nothing else; its results agree with the unit-split kernel's within the bf16 bound, run to run
     bit-identically; forcing it on a shape it cannot run is an error, not a fallback."""
     from timediff_amd import _lib
     sd = random_state(256, 14, 3, 2, 0, seed=3)
     den = den_kernels(sd, dev)
-    assert _choice(den, 100, 272) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 1024, 272) == _lib.LAYER_KERNEL_CLUSTER
-    assert _choice(den, 1025, 272) == _lib.LAYER_KERNEL_UNITS and _choice(den, 100, 3) == _lib.LAYER_KERNEL_UNITS
+    assert _choice(den, 100, 272) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 2048, 272) == _lib.LAYER_KERNEL_CLUSTER
+    assert _choice(den, 2049, 272) == _lib.LAYER_KERNEL_UNITS and _choice(den, 100, 3) == _lib.LAYER_KERNEL_UNITS
     x, t, _ = _inputs(300, 14, 9, 4, seed=9)
     out = {}
     for mode in (_lib.LAYER_KERNEL_CLUSTER, _lib.LAYER_KERNEL_UNITS):

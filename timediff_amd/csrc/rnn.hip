@@ -7,7 +7,7 @@
 
 int td_layer_kernel_mode(void);   // api.cpp
 #ifndef TD_CLUSTER_AUTO_BLOCKS
-#define TD_CLUSTER_AUTO_BLOCKS 64   // x 32 sequences, both directions counted: 1024 bidirectional sequences (7 ms against 13 ms for the unit-split kernel there; equal at 2048)
+#define TD_CLUSTER_AUTO_BLOCKS 128   // x 32 sequences, both directions counted: 2048 bidirectional sequences (training step there 49.4 ms against 52.6 ms with the unit-split forward; equal at 4096)
 #endif
 // rnn_cluster.hip
 size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);

@@ -109,18 +109,33 @@ __global__ __launch_bounds__(256) void td_x_to_plain_kernel(const float *__restr
     }
 }
 
-// act fragments [l][bblk][D*KH][64][8] -> rows (d*hpad + unit), columns l*Bp + b
+// act fragments [l][bblk][D*KH][64][8] -> rows (d*hpad + unit), columns l*Bp + b.  A workgroup takes one step, two
+// neighbouring batch blocks and 16 fragments (256 units): 16-byte reads of whole fragments, transposed through LDS,
+// 16-byte writes of whole 128-byte row segments (the first version gathered 2-byte elements: 0.6 TB/s).
+#define TD_F2P_FRAGS 16
+#define TD_F2P_ROW 72        // bf16 per LDS row: 64 sequences + 8 of padding (rows stay 16-byte aligned, banks spread)
 __global__ __launch_bounds__(256) void td_frags_to_plain_kernel(const __bf16 *__restrict__ act, __bf16 *__restrict__ out, int L,
                                                                 int nbb, int kh, int dirs) {
-    const int Bp = nbb * 32, hpad = kh * 16;
-    const size_t total = (size_t)dirs * hpad * L * Bp;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int b = (int)(i % Bp), l = (int)((i / Bp) % L);
-        const int row = (int)(i / ((size_t)Bp * L));
-        const int d = row / hpad, unit = row % hpad;
-        const int ks = unit / 16, w = unit % 16, hf = (w >> 2) & 1, j = ((w >> 3) << 2) | (w & 3);
-        const size_t frag = ((size_t)l * nbb + b / 32) * (dirs * kh) + d * kh + ks;
-        out[i] = act[frag * 512 + (hf * 32 + (b % 32)) * 8 + j];
+    __shared__ __attribute__((aligned(16))) __bf16 tile[TD_F2P_FRAGS * 16 * TD_F2P_ROW];
+    const int KT = dirs * kh, Bp = nbb * 32, hpad = kh * 16;
+    const size_t cols = (size_t)L * Bp;
+    const int bb0 = blockIdx.x * 2, l = blockIdx.y, f0 = blockIdx.z * TD_F2P_FRAGS;
+    const int nf = min(TD_F2P_FRAGS, KT - f0), nb = min(2, nbb - bb0);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, hf = lane >> 5;
+    for (int fi = wave; fi < 2 * TD_F2P_FRAGS; fi += 4) {
+        const int blk = fi / TD_F2P_FRAGS, f = fi % TD_F2P_FRAGS;
+        if (blk >= nb || f >= nf) continue;
+        const bf16x8 v = *((const bf16x8 *)(act + (((size_t)l * nbb + bb0 + blk) * KT + f0 + f) * 512) + lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[(16 * f + 8 * (j >> 2) + 4 * hf + (j & 3)) * TD_F2P_ROW + blk * 32 + m] = v[j];
+    }
+    __syncthreads();
+    const int seg = t & 7;               // 8 sequences = 16 bytes of a row
+    if (seg * 8 >= nb * 32) return;
+    for (int row = t >> 3; row < nf * 16; row += 32) {
+        const int fg = f0 + row / 16, d = fg / kh, unit = 16 * (fg % kh) + row % 16;
+        const bf16x8 v = *(const bf16x8 *)(tile + row * TD_F2P_ROW + seg * 8);
+        *(bf16x8 *)(out + ((size_t)d * hpad + unit) * cols + (size_t)l * Bp + bb0 * 32 + seg * 8) = v;
     }
 }
 
@@ -155,8 +170,8 @@ extern "C" int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed
                        t.cpad, seq_len, t.Bp);
     TD_LAUNCH_CHECK();
     for (int l = 0; l < cfg->layers; ++l) {
-        hipLaunchKernelGGL(td_frags_to_plain_kernel, dim3(4096), dim3(256), 0, stream, (const __bf16 *)acts[l],
-                           (__bf16 *)(ws + t.plain[l + 1]), seq_len, t.nbb, g.kh, g.dirs);
+        hipLaunchKernelGGL(td_frags_to_plain_kernel, dim3(td_cdiv(t.nbb, 2), seq_len, td_cdiv(g.dirs * g.kh, TD_F2P_FRAGS)), dim3(256), 0,
+                           stream, (const __bf16 *)acts[l], (__bf16 *)(ws + t.plain[l + 1]), seq_len, t.nbb, g.kh, g.dirs);
         TD_LAUNCH_CHECK();
     }
     return TD_OK;
