@@ -34,6 +34,10 @@ import models.ETDiff.gaussian_diffusion as ref_gauss  # noqa: E402
 import models.ETDiff.blocks as ref_blocks  # noqa: E402
 import models.ETDiff.utils as ref_utils  # noqa: E402
 
+# the vectors must come from the reference itself, not from this repository's drop-in modules of the same names
+for _m in (ref_mixed, ref_gauss, ref_blocks, ref_utils):
+    assert os.path.realpath(_m.__file__).startswith(os.path.realpath(REF) + os.sep), f"{_m.__name__} was imported from {_m.__file__}, not from {REF}"
+
 # silence the progress bar of the reference's sampling loop
 ref_mixed.tqdm = lambda it, **kw: it
 ref_gauss.tqdm = lambda it, **kw: it
