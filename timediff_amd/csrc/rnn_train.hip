@@ -6,7 +6,7 @@
 //   per layer, top down:
 //     bptt_sweep  ONE launch for all steps: gate-gradient arithmetic (d a_t as MFMA fragments + plain rows) and
 //                 d h_{t-1} = W_hh^T d a_t on MFMA, state in registers, d a_t exchanged through LDS
-//                 (small batches at H in (224, 256]: td_bptt_cluster_kernel, rnn_cluster_bwd.hip, 8 workgroups per
+//                 (up to 8192 sequences at H in (192, 256]: td_bptt_cluster_kernel, rnn_cluster_bwd.hip, 8 workgroups per
 //                 batch block and direction with W_hh^T resident in registers)
 //     frag_gemm   all steps at once: d x = W_ih^T d a         (gradient for the layer below)
 //     dw_gemm     d W = d a . [x ; h_prev]^T over all (sequence, step) columns   (MFMA, split-K, fp32 atomics)
