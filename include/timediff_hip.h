@@ -263,10 +263,13 @@ TD_API int td_clip_adam_ema(float *param, const float *grad, float *exp_avg, flo
 /* Kernel-selection knobs for tests and measurements, no counterpart in the reference (process-wide, not
  * thread-safe against concurrent launches).
  *   td_set_layer_kernel: which recurrent-layer kernel family runs hidden sizes <= 256.  AUTO picks by batch
- *     (csrc/rnn.hip: the cluster-persistent kernel of rnn_cluster.hip up to 512 sequences at hidden 193..256 --
- *     weights resident in registers, 8 workgroups per 32 sequences exchanging h_t through L2 --, the unit-split
- *     kernel of rnn_wide.hip below ~8192 sequences, the batch-block kernel of rnn_layer.h above); BATCH / UNITS /
- *     CLUSTER force one family (UNITS needs hidden > 32; CLUSTER is an error where it cannot run).
+ *     (csrc/rnn.hip: the cluster-persistent kernel of rnn_cluster.hip up to 2048 bidirectional sequences at hidden
+ *     193..256 -- weights resident in registers, 8 workgroups per 32 sequences exchanging h_t through L2 --, the
+ *     unit-split kernel of rnn_wide.hip below ~8192 sequences, the batch-block kernel of rnn_layer.h above); BATCH /
+ *     UNITS / CLUSTER force one family (UNITS needs hidden > 32; CLUSTER is an error where it cannot run).  The same
+ *     mode steers the BPTT sweep of td_rnn_backward: AUTO / CLUSTER take the cluster sweep of rnn_cluster_bwd.hip
+ *     where it can run (hidden 193..256, at most 16 batch blocks per cluster = 8192 bidirectional sequences), BATCH /
+ *     UNITS the single-workgroup sweep.
  *   td_set_dw_gemm: weight-gradient GEMMs.  AUTO = rocBLAS where the shape has no column remap, the in-tree
  *     split-K MFMA kernel otherwise; KERNEL = the in-tree kernel for every shape. */
 enum { TD_LAYER_KERNEL_AUTO = 0, TD_LAYER_KERNEL_BATCH = 1, TD_LAYER_KERNEL_UNITS = 2, TD_LAYER_KERNEL_CLUSTER = 3 };
