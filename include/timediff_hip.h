@@ -279,6 +279,13 @@ TD_API int td_set_layer_kernel(int32_t mode);
  * (-1: bad cfg, or a forced family that cannot run this shape). */
 TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
 TD_API int td_set_dw_gemm(int32_t mode);
+/* The sampler's head (LayerNorm + FiLM + fc with one FiLM row for the whole batch) fused into the top layer's kernel: the
+ * layer leaves per-direction partial projections and sum h, sum h^2 instead of its activations (csrc/rnn.hip).  AUTO:
+ * td_sample_chain fuses wherever the batch-block kernel family runs the layers (large batches, at least two layers),
+ * td_rnn_forward never does; OFF: nobody does; ON: td_rnn_forward does too where it can (one FiLM row: film_rows == 1 or
+ * film_row given) -- td_rnn_read_hidden then has no activations of the last layer to read. */
+enum { TD_HEAD_FUSION_AUTO = 0, TD_HEAD_FUSION_OFF = 1, TD_HEAD_FUSION_ON = 2 };
+TD_API int td_set_head_fusion(int32_t mode);
 
 /* Measurement aid, no counterpart in the reference: while enabled, every recurrent-layer kernel of the
  * widest kind (layers above the first) launched outside graph capture is bracketed by HIP events on

@@ -47,6 +47,18 @@ def knob():
     L.td_set_layer_kernel(_lib.LAYER_KERNEL_AUTO)
 
 
+@pytest.fixture()
+def fusion():
+    """td_set_head_fusion, restored to AUTO afterwards."""
+    from timediff_amd import _lib
+    L = _lib.lib()
+
+    def set_mode(mode):
+        _lib.check(L.td_set_head_fusion(mode))
+    yield set_mode
+    L.td_set_head_fusion(_lib.HEAD_FUSION_AUTO)
+
+
 def _choice(den, B, L=6):
     from timediff_amd import _lib
     return _lib.lib().td_rnn_layer_kernel_choice(C.byref(den.cfg), B, L)
@@ -148,11 +160,12 @@ def test_families_agree_on_the_same_batch(dev, knob):
     assert np.abs(out[_lib.LAYER_KERNEL_BATCH] - out[_lib.LAYER_KERNEL_UNITS]).max() < BF16_EMUL_ATOL
 
 
-def test_large_batch_chain_graph_equals_stepwise(dev):
-    """The sampler path bench.py runs (diffusion state -> layer-0 fragments -> batch-block layers -> head -> reverse
-    update, replayed as a hipGraph) above the switch: the graph chain equals the eager chain bit for bit, and the
-    first reverse step equals the tensor-level composition (build_input -> forward -> reverse_step_) whose pieces
-    the other tests pin to the oracle."""
+def test_large_batch_chain_graph_equals_stepwise(dev, fusion):
+    """The sampler path bench.py runs (diffusion state -> layer-0 fragments -> batch-block layers with the head fused
+    into the top layer -> reverse update, replayed as a hipGraph) above the switch: the graph chain equals the eager
+    chain bit for bit, and equals the tensor-level composition (build_input -> forward -> reverse_step_) run with the
+    same fused head; with the fusion off the chain equals the composition through td_head_kernel, whose pieces the
+    other tests pin to the oracle; the two chains agree within the rounding of the projection."""
     from timediff_amd import _lib
     from timediff_amd.ops import DiffusionKernels, SamplerKernels
     H, L, T, B = 256, 6, 3, 8192 + 40
@@ -163,24 +176,72 @@ def test_large_batch_chain_graph_equals_stepwise(dev):
     tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
     diff = DiffusionKernels(num, cat, K, L, T, tables, 9, dev)
     sampler = SamplerKernels(den, diff)
-    a = sampler.sample(B, seed=5, patient0=1000)
-    b = sampler.sample(B, seed=5, patient0=1000, use_graph=False)
-    assert torch.equal(a, b)
-    # the same chain composed from the tensor-level entry points
-    z, idx = diff.prior(B, seed=5, patient0=1000)
     film = den.time_film(torch.arange(T, device=dev))
-    for t in reversed(range(T)):
-        mo = den.forward(diff.build_input(z, idx), film=film[t:t + 1])
-        diff.reverse_step_(mo, z, idx, t, seed=5, patient0=1000)
-    want = diff.decode(z, idx)
-    assert torch.equal(a, want)
-    # and the denoiser output of the first step against the oracle on a subset of sequences
+
+    def composed():
+        z, idx = diff.prior(B, seed=5, patient0=1000)
+        for t in reversed(range(T)):
+            mo = den.forward(diff.build_input(z, idx), film=film[t:t + 1])
+            diff.reverse_step_(mo, z, idx, t, seed=5, patient0=1000)
+        return diff.decode(z, idx)
+
+    chains = {}
+    for mode in (_lib.HEAD_FUSION_ON, _lib.HEAD_FUSION_OFF):      # ON: the chain fuses (as under AUTO) and so does forward
+        fusion(mode)
+        a = sampler.sample(B, seed=5, patient0=1000)
+        b = sampler.sample(B, seed=5, patient0=1000, use_graph=False)
+        assert torch.equal(a, b)
+        assert torch.equal(a, composed())
+        chains[mode] = a.cpu().numpy()
+    fusion(_lib.HEAD_FUSION_AUTO)
+    assert np.array_equal(sampler.sample(B, seed=5, patient0=1000).cpu().numpy(), chains[_lib.HEAD_FUSION_ON])
+    on, off = chains[_lib.HEAD_FUSION_ON], chains[_lib.HEAD_FUSION_OFF]
+    # a class that flips at a near-tie changes that sequence's later steps: the chains agree up to a few such sequences
+    assert (np.abs(on[:, num] - off[:, num]) > 2e-3).mean() < 5e-3
+    assert (on[:, cat] != off[:, cat]).mean() < 2e-3
+    # and the denoiser output of the first step against the oracle on a subset of sequences, both ways
     z, idx = diff.prior(B, seed=5, patient0=1000)
     x_in = diff.build_input(z, idx)
-    mo = den.forward(x_in, film=film[T - 1:T]).cpu().numpy()
     rows = np.unique(np.concatenate([np.arange(0, 33), np.arange(0, B, 211), np.arange(B - 40, B)]))
     y16 = orc.Denoiser(sd, bf16=True).forward(x_in.cpu().numpy()[rows], np.full(len(rows), T - 1))
-    assert np.abs(mo[rows] - y16).max() < 2e-2
+    mo = {}
+    for mode in (_lib.HEAD_FUSION_ON, _lib.HEAD_FUSION_OFF):
+        fusion(mode)
+        mo[mode] = den.forward(x_in, film=film[T - 1:T]).cpu().numpy()
+        assert np.abs(mo[mode][rows] - y16).max() < 2e-2
+    assert np.abs(mo[_lib.HEAD_FUSION_ON] - mo[_lib.HEAD_FUSION_OFF]).max() < 1e-3
+
+
+# (H, gru, dirs, C, n_num, B): above each switch to the batch-block family
+FUSED_HEAD = [
+    (256, 1, 2, 14, 4, 8192 + 40),      # GRU
+    (250, 0, 1, 23, 7, 16384 + 40),     # unidirectional, padded width, more than 16 output channels (wider partials)
+    (128, 0, 2, 14, 4, 8192 + 40),      # 4 unit blocks
+    (92, 1, 2, 23, 7, 1024 + 40),       # MIMIC-III width, 3 unit blocks
+    (20, 0, 2, 9, 7, 300),              # one unit block: every head slot follows the block's gate math
+]
+
+
+@pytest.mark.parametrize("H,gru,dirs,Cc,n_num,B", FUSED_HEAD)
+def test_fused_head_matches_head_kernel(H, gru, dirs, Cc, n_num, B, dev, fusion):
+    """td_rnn_layer_kernel<..., HEAD> + td_head_combine_kernel against td_head_kernel on the same layers (one FiLM row
+    for the batch): both project the same bf16 hidden state with fp32-accurate weights, and against the oracle."""
+    from timediff_amd import _lib
+    L = 5
+    sd = random_state(H, Cc, 2, dirs, gru, seed=H + B)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_BATCH
+    x, _, _ = _inputs(B, Cc, L, n_num, seed=B)
+    film = den.time_film(cu(np.array([321]), dev))
+    out = {}
+    for mode in (_lib.HEAD_FUSION_ON, _lib.HEAD_FUSION_OFF):
+        fusion(mode)
+        out[mode] = den.forward(cu(x, dev), film=film).cpu().numpy()
+        assert np.isfinite(out[mode]).all()
+    assert np.abs(out[_lib.HEAD_FUSION_ON] - out[_lib.HEAD_FUSION_OFF]).max() < 1e-3
+    rows = np.unique(np.concatenate([np.arange(0, 33), np.arange(0, B, 509), np.arange(B - 40, B)]))
+    y16 = orc.Denoiser(sd, bf16=True).forward(x[rows], np.full(len(rows), 321))
+    assert np.abs(out[_lib.HEAD_FUSION_ON][rows] - y16).max() < 2e-2
 
 
 # ---------------------------------------------------------------------------------------------

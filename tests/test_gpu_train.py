@@ -144,3 +144,35 @@ def test_gaussian_training_step(dev, tmp_path):
     assert (et.flat_param != before).float().mean() > 0.99      # every parameter received a gradient
     out = et.ema.ema_model.sample(batch_size=5)
     assert out.shape == (5, 6, 20) and torch.isfinite(out).all()
+
+
+def test_checkpoint_written_beside_training(dev, tmp_path):
+    """save_weights(block=False): the snapshot is taken in stream order, the file is written by a thread while further
+    optimizer steps change the weights; the file holds the weights, EMA and Adam moments of the step it was asked at,
+    in the reference's dict layout (et_diff.py:208-216), and a fresh trainer resumes from it."""
+    g = load_golden("train_steps_eicu")
+    L, H, N, T, B, ga = [int(v) for v in g["cfg"]]
+    et = _build(g, dev, ga, 1e-3, tmp_path, T, L, H, N)
+    for _ in range(3):
+        et.train_step()
+    want = {k: getattr(et, k).clone() for k in ("flat_param", "flat_ema", "exp_avg", "exp_avg_sq")}
+    step = et.step
+    et.save_weights(block=False)
+    for _ in range(3):                      # the weights move on while the writer runs
+        et.train_step()
+    et.wait_for_checkpoint()
+    assert not torch.equal(et.flat_param, want["flat_param"])
+    ck = torch.load(et.check_point_path, map_location="cpu", weights_only=True)
+    assert sorted(ck) == ["diff_model", "diff_step", "ema", "opt", "scaler"] and ck["diff_step"] == step
+    assert list(ck["diff_model"].keys()) == list(et.model.state_dict().keys())
+    assert list(ck["ema"].keys()) == list(et.ema.state_dict().keys())
+    et2 = _build(g, dev, ga, 1e-3, tmp_path, T, L, H, N)
+    et2.load(et.check_point_path)
+    for k, v in want.items():
+        assert torch.equal(getattr(et2, k), v), k
+    assert et2.step == step and et2.opt_step == step
+    # a second checkpoint reuses the pinned staging buffers; a writer error surfaces at the join
+    et.check_point_path = str(tmp_path / "no_such_dir" / "x.pt")
+    et.save_weights(block=False)
+    with pytest.raises(Exception):
+        et.wait_for_checkpoint()

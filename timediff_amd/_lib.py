@@ -22,6 +22,7 @@ MISC_KEYS = ["time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_
 
 LAYER_KERNEL_AUTO, LAYER_KERNEL_BATCH, LAYER_KERNEL_UNITS, LAYER_KERNEL_CLUSTER = 0, 1, 2, 3     # td_set_layer_kernel
 DW_GEMM_AUTO, DW_GEMM_KERNEL = 0, 1                                     # td_set_dw_gemm
+HEAD_FUSION_AUTO, HEAD_FUSION_OFF, HEAD_FUSION_ON = 0, 1, 2             # td_set_head_fusion
 
 
 class RnnConfig(C.Structure):
@@ -86,6 +87,7 @@ _SIGS = {
     "td_set_layer_kernel": (C.c_int, [_I]),
     "td_rnn_layer_kernel_choice": (C.c_int, [C.POINTER(RnnConfig), _I, _I]),
     "td_set_dw_gemm": (C.c_int, [_I]),
+    "td_set_head_fusion": (C.c_int, [_I]),
     "td_profile_enable": (C.c_int, [_I]),
     "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
 }

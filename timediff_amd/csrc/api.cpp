@@ -21,8 +21,19 @@ extern "C" int td_version(void) { return 200; }
 // ---------------------------------------------------------------------------------------------
 static int g_layer_kernel = TD_LAYER_KERNEL_AUTO;
 static int g_dw_gemm = TD_DW_GEMM_AUTO;
+static int g_head_fusion = TD_HEAD_FUSION_AUTO;
+int td_head_fusion_mode(void) { return g_head_fusion; }
 int td_layer_kernel_mode(void) { return g_layer_kernel; }
 int td_dw_gemm_mode(void) { return g_dw_gemm; }
+
+extern "C" int td_set_head_fusion(int32_t mode) {
+    if (mode != TD_HEAD_FUSION_AUTO && mode != TD_HEAD_FUSION_OFF && mode != TD_HEAD_FUSION_ON) {
+        td_set_error("td_set_head_fusion: unknown mode %d", mode);
+        return TD_ERR_INVALID;
+    }
+    g_head_fusion = mode;
+    return TD_OK;
+}
 
 extern "C" int td_set_layer_kernel(int32_t mode) {
     if (mode != TD_LAYER_KERNEL_AUTO && mode != TD_LAYER_KERNEL_BATCH && mode != TD_LAYER_KERNEL_UNITS && mode != TD_LAYER_KERNEL_CLUSTER) {

@@ -6,6 +6,7 @@
 #include <math.h>
 
 int td_layer_kernel_mode(void);   // api.cpp
+int td_head_fusion_mode(void);    // api.cpp
 #ifndef TD_CLUSTER_AUTO_BLOCKS
 #define TD_CLUSTER_AUTO_BLOCKS 128   // x 32 sequences, both directions counted: 2048 bidirectional sequences (training step there 49.4 ms against 52.6 ms with the unit-split forward; equal at 4096)
 #endif
@@ -79,12 +80,35 @@ static void td_ws_layout(const TdRnnGeom &g, int batch, int L, size_t *x0_bytes,
     *act_bytes = (size_t)L * nbb * (g.dirs * g.kh) * TD_FRAG_BYTES;
 }
 
+// Fused head (the batch-block family's top layer, one FiLM row shared by the batch: the sampler): the top layer's weight
+// stream with the folded head fragments behind it, and the per-(step, block, direction) partials the layer kernel leaves
+// instead of its activations.  Both live behind the state scratch in the workspace.
+struct TdHeadFuse {
+    size_t stream_off, part_off, total;   // byte offsets in the workspace, and the workspace size with them
+    size_t hdir_bytes;                    // one direction of the extended stream
+    int hp_stride;                        // floats per lane of the partials
+    bool possible;                        // the width and depth have the kernel at all
+};
+static TdHeadFuse td_head_fuse_layout(const td_rnn_config *cfg, const TdRnnGeom &g, int batch, int L) {
+    TdHeadFuse h;
+    size_t x0, act;
+    td_ws_layout(g, batch, L, &x0, &act);
+    const size_t base = (x0 + 2 * act + g.dirs * td_state_dir_bytes(g, batch) + 255) & ~(size_t)255;
+    h.possible = g.nu <= 8 && cfg->layers >= 2;
+    h.hp_stride = cfg->c_out <= 16 ? 12 : 20;
+    const size_t nfr = (size_t)g.g1.nf + 2 * g.kh;
+    h.hdir_bytes = ((nfr + TD_STAGE_FRAGS - 1) / TD_STAGE_FRAGS) * TD_STAGE_BYTES;
+    h.stream_off = base;
+    h.part_off = base + (h.possible ? g.dirs * h.hdir_bytes : 0);
+    const size_t nbb = (size_t)td_cdiv(batch, TD_WAVE_BATCH);
+    h.total = h.part_off + (h.possible ? (size_t)L * nbb * g.dirs * 64 * h.hp_stride * sizeof(float) : 0);
+    return h;
+}
+
 extern "C" size_t td_rnn_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len) {
     TdRnnGeom g;
     if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0 || seq_len <= 0) return 0;
-    size_t x0, act;
-    td_ws_layout(g, batch, seq_len, &x0, &act);
-    return x0 + 2 * act + g.dirs * td_state_dir_bytes(g, batch);
+    return td_head_fuse_layout(cfg, g, batch, seq_len).total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,6 +491,116 @@ __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused head (sampler): y = fc(FiLM(LayerNorm(h))) with ONE FiLM row for the whole batch is linear in h up to the
+// LayerNorm statistics:
+//     y[c] = rstd * ( sum_f w'[c][f] h[f]  -  mu * sum_f w'[c][f] )  +  sum_f fc_w[c][f] (ln_b[f] (1 + scale[f]) + shift[f])  +  fc_b[c]
+//     w'[c][f] = fc_w[c][f] * ln_w[f] * (1 + scale[f])
+// The top layer's kernel (rnn_layer.h, HEAD) multiplies w' -- as bf16 hi + lo A fragments appended to its weight stream --
+// with the h_t fragments it has just produced and leaves, per direction, the partial projection and sum h, sum h^2;
+// td_head_combine_kernel adds the directions.  The layer's activations (4.5 GB per reverse step at the bench shape) are
+// neither written nor read.
+// ---------------------------------------------------------------------------------------------
+struct TdHeadFoldParams {
+    const char *src;          // the top layer's packed stream, direction 0
+    size_t src_dir;
+    char *dst;                // extended stream, direction 0
+    size_t dst_dir;
+    const float *ln_w, *fc_w, *film;
+    const int32_t *film_row;
+    int nfb, H, kh, dirs, c_out;
+};
+
+__global__ __launch_bounds__(256) void td_head_fold_kernel(TdHeadFoldParams p) {
+    const int DH = p.dirs * p.H;
+    const float *film = p.film + (size_t)(p.film_row ? p.film_row[0] : 0) * 2 * DH;
+    // the unit blocks' fragments, unchanged (16 bytes per thread)
+    const size_t nvec = (size_t)p.dirs * p.nfb * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i / ((size_t)p.nfb * 64));
+        const size_t r = i % ((size_t)p.nfb * 64);
+        ((bf16x8 *)(p.dst + (size_t)d * p.dst_dir))[r] = ((const bf16x8 *)(p.src + (size_t)d * p.src_dir))[r];
+    }
+    // the head fragments: [k-step][hi | lo], A operand: lane (row = channel, hf), element j <-> unit of B's k index 8 hf + j
+    const size_t nh = (size_t)p.dirs * 2 * p.kh * 512;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i % 8), ln = (int)((i / 8) % 64), f = (int)((i / 512) % (2 * p.kh)), d = (int)(i / ((size_t)512 * 2 * p.kh));
+        const int c = ln & 31, hf = ln >> 5, ks = f >> 1;
+        const int unit = 16 * ks + 8 * (j >> 2) + 4 * hf + (j & 3);
+        float w = 0.f;
+        if (c < p.c_out && unit < p.H) {
+            const int feat = d * p.H + unit;
+            w = p.fc_w[(size_t)c * DH + feat] * p.ln_w[feat] * (film[feat] + 1.0f);
+        }
+        const __bf16 hi = (__bf16)w;
+        ((__bf16 *)(p.dst + (size_t)d * p.dst_dir + ((size_t)p.nfb + f) * TD_FRAG_BYTES))[ln * 8 + j] = (f & 1) ? (__bf16)(w - (float)hi) : hi;
+    }
+}
+
+struct TdHeadCombineParams {
+    const float *hpart;
+    const float *ln_w, *ln_b, *fc_w, *fc_b, *film;
+    const int32_t *film_row;
+    float *y;
+    int hp_stride, B, L, nbb, H, dirs, c_out;
+};
+
+__global__ __launch_bounds__(256) void td_head_combine_kernel(TdHeadCombineParams p) {
+    __shared__ float s_wsum[32], s_cst[32];
+    const int DH = p.dirs * p.H;
+    const float *film = p.film + (size_t)(p.film_row ? p.film_row[0] : 0) * 2 * DH;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
+    // per channel: sum_f w'[c][f] (of the hi + lo values the layer kernel multiplied) and the constant term
+    for (int c = wave; c < p.c_out; c += 4) {
+        float ws = 0.f, cs = 0.f;
+        for (int f = lane; f < DH; f += 64) {
+            const float sc = film[f] + 1.0f, fw = p.fc_w[(size_t)c * DH + f];
+            const float w = fw * p.ln_w[f] * sc;
+            const __bf16 hi = (__bf16)w;
+            ws += (float)hi + (float)(__bf16)(w - (float)hi);
+            cs += fw * (p.ln_b[f] * sc + film[DH + f]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ws += __shfl_xor(ws, o); cs += __shfl_xor(cs, o); }
+        if (lane == 0) { s_wsum[c] = ws; s_cst[c] = cs + p.fc_b[c]; }
+    }
+    __syncthreads();
+    const size_t ntask = (size_t)p.L * p.nbb;
+    const int nreg = p.hp_stride > 12 ? 16 : 8;
+    for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
+        const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
+        const int b = bblk * 32 + m;
+        float acc[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int d = 0; d < p.dirs; ++d) {
+            const float *hp = p.hpart + ((task * p.dirs + d) * 64 + lane) * p.hp_stride;
+            const f32x4 a0 = *(const f32x4 *)hp, a1 = *(const f32x4 *)(hp + 4), st = *(const f32x4 *)(hp + p.hp_stride - 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i] += a0[i]; acc[4 + i] += a1[i]; }
+            if (nreg > 8) {
+                const f32x4 a2 = *(const f32x4 *)(hp + 8), a3 = *(const f32x4 *)(hp + 12);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[8 + i] += a2[i]; acc[12 + i] += a3[i]; }
+            }
+            s1 += st[0];
+            s2 += st[1];
+        }
+        s1 += __shfl_xor(s1, 32);      // lanes m and m + 32 hold the two halves of sequence m's units
+        s2 += __shfl_xor(s2, 32);
+        const float mu = s1 / (float)DH;
+        const float var = fmaxf(s2 / (float)DH - mu * mu, 0.f);
+        const float rstd = rsqrtf(var + 1e-5f);
+        if (b < p.B) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (r < nreg && c < p.c_out) p.y[((size_t)b * p.c_out + c) * p.L + l] = rstd * (acc[r] - mu * s_wsum[c]) + s_cst[c];
+            }
+        }
+    }
+}
+
 // parity/debug: fragments -> (B, L, D*H) fp32
 __global__ void td_unpack_hidden_kernel(const char *act, float *hidden, int B, int L, int nbb, int H, int kh, int dirs) {
     const size_t total = (size_t)B * L * dirs * H;
@@ -486,8 +620,8 @@ __global__ void td_unpack_hidden_kernel(const char *act, float *hidden, int B, i
 // ---------------------------------------------------------------------------------------------
 // layer dispatch (one translation unit per kernel family: rnn_launch.h, rnn_layer_inst.hip)
 // ---------------------------------------------------------------------------------------------
-int td_launch_layer_infer(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
-    return td_launch_layer_dispatch(gru, 0, nu, p, layer0, kxsel, stream);
+int td_launch_layer_infer(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream, bool head = false) {
+    return td_launch_layer_dispatch(gru, 0, nu, p, layer0, kxsel, stream, head);
 }
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream);
 // rnn_wide.hip: hidden sizes above 256
@@ -500,8 +634,15 @@ void td_profile_end(int slot, void *stream);
 
 // Runs pack-input + all recurrent layers.  acts[l] receives layer l's output fragments; saves[l] (training)
 // the per-step gate activations.  Inference ping-pongs two activation buffers.
+// fuse (optional): the top layer runs its fused-head variant on fuse->stream and leaves fuse->hpart instead of acts[top]
+struct TdHeadFuseRun {
+    const char *stream;
+    size_t hdir_bytes;
+    float *hpart;
+    int hp_stride;
+};
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
-                         char *const *acts, float *const *saves, float *state, hipStream_t stream) {
+                         char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse = nullptr) {
     TdRnnGeom g;
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
@@ -526,7 +667,13 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
         p.save_dir_stride = (size_t)L * nbb * g.nu * 5 * 1024;
         p.state = state;
         p.state_dir_stride = td_state_dir_bytes(g, batch) / sizeof(float);
+        p.hpart = nullptr; p.hp_stride = 0;
         const int kxsel = l == 0 ? g.kx0 : g.dirs;
+        const bool head = fuse && l == cfg->layers - 1;
+        if (head) {
+            p.wpacked = fuse->stream; p.dir_stride = fuse->hdir_bytes;
+            p.hpart = fuse->hpart; p.hp_stride = fuse->hp_stride;
+        }
         if (td_layer_kernel_mode() == TD_LAYER_KERNEL_CLUSTER && !td_use_cluster(g, nbb, L)) {
             td_set_error("the cluster kernel was forced but cannot run hidden = %d, batch = %d, seq_len = %d", cfg->hidden, batch, L);
             return TD_ERR_UNSUPPORTED;
@@ -544,49 +691,13 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
             rc = td_launch_layer_save(cfg->gru, g.nu, p, l == 0, kxsel, stream);
         } else {
             const int slot = l > 0 ? td_profile_begin(stream) : -1;
-            rc = td_launch_layer_infer(cfg->gru, g.nu, p, l == 0, kxsel, stream);
+            rc = td_launch_layer_infer(cfg->gru, g.nu, p, l == 0, kxsel, stream, head);
             td_profile_end(slot, stream);
         }
         if (rc != TD_OK) return rc;
         in = acts[l];
     }
     return TD_OK;
-}
-
-int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, void *workspace,
-                      hipStream_t stream, const char **last_act) {
-    TdRnnGeom g;
-    int rc = td_rnn_geom(cfg, &g);
-    if (rc != TD_OK) return rc;
-    size_t x0_bytes, act_bytes;
-    td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
-    char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
-    char *acts[16];
-    for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
-    *last_act = acts[cfg->layers - 1];
-    return td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, (float *)(actB + act_bytes), stream);
-}
-
-// Sampler path: the layer-0 fragments come straight from the diffusion state (z, class ids).
-int td_rnn_run_layers_state(const td_rnn_config *cfg, const void *packed, const td_diffusion_config *dcfg, const float *z,
-                            const uint8_t *idx, int batch, int L, void *workspace, hipStream_t stream, const char **last_act) {
-    TdRnnGeom g;
-    int rc = td_rnn_geom(cfg, &g);
-    if (rc != TD_OK) return rc;
-    size_t x0_bytes, act_bytes;
-    td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
-    char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
-    int sumk = 0;
-    for (int v = 0; v < dcfg->n_cat; ++v) sumk += dcfg->num_classes[v];
-    TD_REQUIRE(dcfg->n_num + sumk == cfg->c_in && dcfg->seq_len == L, "diffusion state does not match the denoiser input");
-    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
-    hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), 0, stream, *dcfg, sumk, z, idx, x0,
-                       batch, nbb, g.kx0);
-    TD_LAUNCH_CHECK();
-    char *acts[16];
-    for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
-    *last_act = acts[cfg->layers - 1];
-    return td_rnn_run_layers_ex(cfg, packed, nullptr, batch, L, x0, acts, nullptr, (float *)(actB + act_bytes), stream);
 }
 
 template <int KT>
@@ -626,16 +737,80 @@ int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *
     return TD_ERR_UNSUPPORTED;
 }
 
+// Does a call take the fused head?  Chain: wherever the batch-block family runs the layers and the batch shares one FiLM
+// row.  Tensor-level forward: only when td_set_head_fusion asked for it (td_rnn_read_hidden needs the activations).
+static bool td_head_fusable(const td_rnn_config *cfg, const TdRnnGeom &g, int batch, int L, int film_rows, const int32_t *film_row,
+                            bool chain) {
+    const int mode = td_head_fusion_mode();
+    if (mode == TD_HEAD_FUSION_OFF || (mode == TD_HEAD_FUSION_AUTO && !chain)) return false;
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    if (!(g.nu <= 8 && cfg->layers >= 2 && g.dirs * g.kh <= 32)) return false;
+    if (!(film_row || film_rows == 1)) return false;
+    return !td_use_cluster(g, nbb, L) && !td_use_wide(g, nbb);
+}
+
+// The whole denoiser: layer-0 fragments (from x, or from the sampler's diffusion state z / idx), the recurrent layers, the
+// head -> y (B, C_out, L).
+int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,
+                   const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, const float *film, int film_rows,
+                   const int32_t *film_row, int batch, int L, float *y, void *workspace, hipStream_t stream, bool chain) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    size_t x0_bytes, act_bytes;
+    td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
+    char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    if (!x) {   // sampler path: the layer-0 fragments come straight from the diffusion state
+        int sumk = 0;
+        for (int v = 0; v < dcfg->n_cat; ++v) sumk += dcfg->num_classes[v];
+        TD_REQUIRE(dcfg->n_num + sumk == cfg->c_in && dcfg->seq_len == L, "diffusion state does not match the denoiser input");
+        hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), 0, stream, *dcfg, sumk, z, idx, x0,
+                           batch, nbb, g.kx0);
+        TD_LAUNCH_CHECK();
+    }
+    char *acts[16];
+    for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;
+    float *state = (float *)(actB + act_bytes);
+    if (!td_head_fusable(cfg, g, batch, L, film_rows, film_row, chain)) {
+        rc = td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, state, stream);
+        if (rc != TD_OK) return rc;
+        return td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, film_rows, film_row, batch, L, y, stream);
+    }
+    const TdHeadFuse hl = td_head_fuse_layout(cfg, g, batch, L);
+    const int top = cfg->layers - 1;
+    TdHeadFoldParams fp;
+    fp.src = (const char *)packed + g.layer_off[top]; fp.src_dir = g.g1.dir_bytes;
+    fp.dst = (char *)workspace + hl.stream_off; fp.dst_dir = hl.hdir_bytes;
+    fp.ln_w = misc[TD_LN_W]; fp.fc_w = misc[TD_FC_W]; fp.film = film; fp.film_row = film_row;
+    fp.nfb = g.g1.nf; fp.H = cfg->hidden; fp.kh = g.kh; fp.dirs = g.dirs; fp.c_out = cfg->c_out;
+    hipLaunchKernelGGL(td_head_fold_kernel, dim3(256), dim3(256), 0, stream, fp);
+    TD_LAUNCH_CHECK();
+    TdHeadFuseRun run;
+    run.stream = fp.dst; run.hdir_bytes = hl.hdir_bytes;
+    run.hpart = (float *)((char *)workspace + hl.part_off); run.hp_stride = hl.hp_stride;
+    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, state, stream, &run);
+    if (rc != TD_OK) return rc;
+    TdHeadCombineParams cp;
+    cp.hpart = run.hpart; cp.ln_w = misc[TD_LN_W]; cp.ln_b = misc[TD_LN_B]; cp.fc_w = misc[TD_FC_W]; cp.fc_b = misc[TD_FC_B];
+    cp.film = film; cp.film_row = film_row; cp.y = y; cp.hp_stride = hl.hp_stride;
+    cp.B = batch; cp.L = L; cp.nbb = nbb; cp.H = cfg->hidden; cp.dirs = g.dirs; cp.c_out = cfg->c_out;
+    const size_t ntask = (size_t)L * nbb;
+    int blocks = (int)((ntask + 3) / 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(td_head_combine_kernel, dim3(blocks), dim3(256), 0, stream, cp);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 extern "C" int td_rnn_forward(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,
                               const float *film, int32_t film_rows, const int32_t *film_row, int32_t batch,
                               int32_t seq_len, float *y, void *workspace, void *stream) {
     TD_REQUIRE(cfg && packed && misc && x && film && y && workspace, "NULL argument");
     TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
     TD_REQUIRE(film_rows == 1 || film_rows == batch || film_row, "film_rows must be 1 or batch");
-    const char *act = nullptr;
-    int rc = td_rnn_run_layers(cfg, packed, x, batch, seq_len, workspace, (hipStream_t)stream, &act);
-    if (rc != TD_OK) return rc;
-    return td_rnn_head(cfg, misc, act, film, film_rows, film_row, batch, seq_len, y, (hipStream_t)stream);
+    return td_rnn_denoise(cfg, packed, misc, x, nullptr, nullptr, nullptr, film, film_rows, film_row, batch, seq_len, y, workspace,
+                          (hipStream_t)stream, false);
 }
 
 extern "C" int td_rnn_read_hidden(const td_rnn_config *cfg, const void *workspace, int32_t batch, int32_t seq_len,

@@ -71,13 +71,19 @@ __device__ __forceinline__ float td_unpark(float a) {
 #define TD_RING_DEPTH 4   // ring stages
 #define TD_RING_BYTES (TD_RING_FRAGS * TD_FRAG_BYTES)
 
-template <int NU, int KX, bool L0, bool GRU>
+// HEAD (the sampler's top layer): the step's weight stream ends with 2 KH more fragments, the hi and lo parts of
+// fc_w * ln_w * (1 + FiLM scale) per 16 hidden units, and the kernel multiplies them with the h_t fragments it has just
+// produced: it leaves per (step, batch block, direction) the partial projection and sum h, sum h^2 instead of the
+// activations (rnn.hip: td_head_fold_kernel, td_head_combine_kernel).
+template <int NU, int KX, bool L0, bool GRU, bool HEAD = false>
 struct TdLayerTraits {
     static constexpr int NG = GRU ? 3 : 4;
     static constexpr int KH = 2 * NU;
     static constexpr int XFR = L0 ? 2 * KX : KX;
     static constexpr int FU = 4 + (KH + XFR) * NG;  // 4 bias fragments lead each unit block
-    static constexpr int NF = NU * FU;
+    static constexpr int NFB = NU * FU;             // fragments of the unit blocks
+    static constexpr int HF = HEAD ? 2 * KH : 0;    // head fragments behind them
+    static constexpr int NF = NFB + HF;             // weight fragments per time step
     static constexpr int NS = (NF + TD_RING_FRAGS - 1) / TD_RING_FRAGS;  // ring stages per time step
     static constexpr int LDS_W = TD_RING_DEPTH * TD_RING_BYTES;
     static constexpr int LDS_X = L0 ? 0 : TD_BLOCK_WAVES * KX * TD_FRAG_BYTES;  // this step's input fragments
@@ -90,10 +96,11 @@ struct TdLayerTraits {
 // ---------------------------------------------------------------------------------------------
 // compile-time instruction schedule of one time step
 // ---------------------------------------------------------------------------------------------
-template <int NU, int KX, bool L0, bool GRU, bool SAVE>
+template <int NU, int KX, bool L0, bool GRU, bool SAVE, bool HEAD = false>
 struct TdSched {
-    using T = TdLayerTraits<NU, KX, L0, GRU>;
-    static constexpr int NG = T::NG, KH = T::KH, FU = T::FU, NF = T::NF, NS = T::NS, APD = T::APD;
+    using T = TdLayerTraits<NU, KX, L0, GRU, HEAD>;
+    static constexpr int NG = T::NG, KH = T::KH, FU = T::FU, NF = T::NF, NFB = T::NFB, HF = T::HF, NS = T::NS, APD = T::APD;
+    static_assert(!(HEAD && SAVE) && !(HEAD && L0), "the fused head is an inference variant of the layers above the first");
     static constexpr int NOPS = GRU ? 7 : 12;  // gate-math micro-ops per accumulator row
     static constexpr int NQ = 16 * NOPS;       // per 32-unit block
     // Pieces issued while stage j is read belong to stage j + LEAD and land in the buffer stage j - 2 was read
@@ -136,6 +143,8 @@ struct TdSched {
     // room for gate-math micro-ops beside slot F's MFMA (block 0 of a step has no previous block to finish)
     static constexpr int capacity(int F) {
         if (F / FU == 0) return 0;
+        // head slots: the last four multiply the last block's own h_t, i.e. follow every one of its gate micro-ops
+        if (F >= NFB && F - NFB >= HF - 4) return 0;
         if (boundary(F)) return 0;  // wait + barrier
         if (wpieces(F) > 0 || xdma_of(F) >= 0) return TD_CAP_VMEM;
         return TD_CAP_FREE;
@@ -157,6 +166,17 @@ struct TdSched {
                 t.qend[F] = total ? (short)((long)cum * NQ / total) : 0;
             }
         }
+        if (HF > 0) {   // the head slots carry the last block's gate micro-ops
+            int total = 0;
+            for (int f = 0; f < HF; ++f) total += capacity(NFB + f);
+            int cum = 0;
+            for (int f = 0; f < HF; ++f) {
+                const int F = NFB + f;
+                t.qbeg[F] = total ? (short)((long)cum * NQ / total) : (short)NQ;
+                cum += capacity(F);
+                t.qend[F] = total ? (short)((long)cum * NQ / total) : (short)NQ;
+            }
+        }
         // Stage j opens in slot Fb = 8j - APD.  Its two pieces went out while stage j - LEAD (a full stage) was
         // read, the second one in slot Fl = 8(j - LEAD) + 3 - APD.  Everything issued after that piece and
         // before the wait is younger than both: inside slot Fl the input-fragment piece and the output stores
@@ -168,7 +188,7 @@ struct TdSched {
 #ifndef TD_WAIT_ALL
             if (j >= LEAD && Fl >= 0) {
                 for (int F = Fl; F < Fb; ++F) {
-                    int st = (t.qend[F] == NQ && t.qbeg[F] < NQ) ? 2 : 0;
+                    int st = (!HEAD && t.qend[F] == NQ && t.qbeg[F] < NQ) ? 2 : 0;   // the block's two output fragments
                     for (int q = t.qbeg[F]; q < t.qend[F]; ++q) st += save_stores(q);
                     n += (F > Fl ? wpieces(F) : 0) + (xdma_of(F) >= 0 ? 1 : 0) + st;
                 }
@@ -181,11 +201,11 @@ struct TdSched {
     static constexpr Tab tab = make();
 };
 
-template <int NU, int KX, bool L0, bool GRU, bool SAVE = false>
+template <int NU, int KX, bool L0, bool GRU, bool SAVE = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
-    using T = TdLayerTraits<NU, KX, L0, GRU>;
-    using S = TdSched<NU, KX, L0, GRU, SAVE>;
-    constexpr int NG = T::NG, KH = T::KH, XFR = T::XFR, FU = T::FU, NS = T::NS, NF = T::NF, APD = T::APD;
+    using T = TdLayerTraits<NU, KX, L0, GRU, HEAD>;
+    using S = TdSched<NU, KX, L0, GRU, SAVE, HEAD>;
+    constexpr int NG = T::NG, KH = T::KH, XFR = T::XFR, FU = T::FU, NS = T::NS, NF = T::NF, NFB = T::NFB, HF = T::HF, APD = T::APD;
     constexpr int NOPS = S::NOPS, NQ = S::NQ, LEAD = S::LEAD;
     __shared__ __attribute__((aligned(16))) char lds[T::LDS_TOTAL];
 
@@ -278,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         float *svb = nullptr;
         if constexpr (SAVE) svb = p.save + (size_t)dir * p.save_dir_stride + (((size_t)l * p.nbb + bb) * NU * 5) * 1024 + lane * 16;
 
+        float hs1 = 0.f, hs2 = 0.f;   // HEAD: sum h_t and sum h_t^2 over this lane's units (of the bf16 values the head would read)
         // the per-step base pointer is laundered so that nothing derived from it is loop-invariant:
         // otherwise every stage's DMA base gets hoisted out of the time loop and spilled
         const char *wstep = wwave;
@@ -370,11 +391,17 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 // rows r-1, r are neighbours in the bf16 fragment: convert them as a pair
                 if constexpr ((r & 1) == 0) hprev = hval;
                 else {
-                    hn[2 * ub + (r >> 3)][(r & 7) - 1] = (__bf16)hprev;
-                    hn[2 * ub + (r >> 3)][r & 7] = (__bf16)hval;
+                    const __bf16 b0 = (__bf16)hprev, b1 = (__bf16)hval;
+                    hn[2 * ub + (r >> 3)][(r & 7) - 1] = b0;
+                    hn[2 * ub + (r >> 3)][r & 7] = b1;
+                    if constexpr (HEAD) {
+                        const float f0 = (float)b0, f1 = (float)b1;
+                        hs1 += f0 + f1;
+                        hs2 = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, hs2));
+                    }
                 }
             }
-            if constexpr (q == NQ - 1) {
+            if constexpr (q == NQ - 1 && !HEAD) {
                 // h_t of this block goes to HBM for the next layer right away (streaming store: it must not push
                 // the weights out of this XCD's L2)
                 __builtin_nontemporal_store(hn[2 * ub], (bf16x8 *)(op + (2 * ub) * TD_FRAG_BYTES));
@@ -450,8 +477,42 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             });
         });
 
-        // the last block's gates have no MFMAs left to hide behind
-        td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
+        if constexpr (!HEAD) {
+            // the last block's gates have no MFMAs left to hide behind
+            td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
+        } else {
+            // head slots: partial projection of h_t, k-step by k-step (hi and lo part of the folded weights); the k-steps of
+            // the blocks before the last run beside the last block's gate math, the last block's own four slots after it
+            f32x16 &hacc = acc[NU & 1][0];     // the accumulator set the last block does not use
+            // a single unit block: every head slot multiplies that block's own h_t, its gate math has nothing to hide behind
+            if constexpr (HF <= 4) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
+            td_static_for<HF>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                constexpr int F = NFB + f;
+                if constexpr (f == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+                }
+                const bf16x8 a = A[F % APD];
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hn[f / 2], hacc, 0, 0, 0);
+                if constexpr (S::refill_of(F) >= 0)
+                    A[F % APD] = refill(std::integral_constant<int, (S::refill_of(F) >= 0 ? S::refill_of(F) : 0)>{});
+                constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
+                td_static_for<q1 - q0>([&](auto jc) {
+                    gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{});
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // accumulator row r of lane (m, hf) = output channel (r&3) + 8(r>>2) + 4hf of sequence m
+            float *hp = p.hpart + ((((size_t)l * p.nbb + bb) * p.dirs + dir) * 64 + lane) * p.hp_stride;
+            *(f32x4 *)hp = f32x4{hacc[0], hacc[1], hacc[2], hacc[3]};
+            *(f32x4 *)(hp + 4) = f32x4{hacc[4], hacc[5], hacc[6], hacc[7]};
+            if (p.hp_stride > 12) {   // more than 16 output channels
+                *(f32x4 *)(hp + 8) = f32x4{hacc[8], hacc[9], hacc[10], hacc[11]};
+                *(f32x4 *)(hp + 12) = f32x4{hacc[12], hacc[13], hacc[14], hacc[15]};
+            }
+            *(f32x4 *)(hp + p.hp_stride - 4) = f32x4{hs1, hs2, 0.f, 0.f};
+        }
 
         // h_t replaces h_{t-1} only now: every unit block above consumed the old one
 #pragma unroll

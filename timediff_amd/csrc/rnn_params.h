@@ -16,4 +16,8 @@ struct TdLayerParams {
     // wide layers (rnn_wide.hip) only: recurrent state between steps, [dir][bblk][u][64 lanes][16] fp32
     float *state;
     size_t state_dir_stride;  // floats
+    // HEAD kernels (the sampler's top layer) only: per (step, batch block, direction, lane) hp_stride floats: the partial
+    // projection's accumulator registers (8, or 16 with more than 16 output channels), then sum h, sum h^2, 0, 0
+    float *hpart;
+    int hp_stride;            // 12 or 20
 };

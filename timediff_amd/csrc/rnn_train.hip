@@ -20,8 +20,9 @@ int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, i
 
 size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);   // rnn_cluster.hip
 int td_layer_kernel_mode(void);   // api.cpp
+struct TdHeadFuseRun;   // rnn.hip: the sampler's fused head, not used in training
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
-                         char *const *acts, float *const *saves, float *state, hipStream_t stream);
+                         char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse);
 // gemm_lib.cpp (rocBLAS)
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
                    int nsplit, float *partial, hipStream_t stream);
@@ -161,7 +162,7 @@ extern "C" int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed
     }
     // wide layers: the recurrent-state scratch is the d c carry region of the backward pass ([bblk][u][1024] fp32 per
     // direction, contiguous: td_train_layout)
-    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream);
+    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream, nullptr);
     if (rc != TD_OK) return rc;
     rc = td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, batch, nullptr, batch, seq_len, y, stream);
     if (rc != TD_OK) return rc;

@@ -6,12 +6,9 @@
 
 #include <string.h>
 
-int td_rnn_run_layers(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, void *workspace,
-                      hipStream_t stream, const char **last_act);
-int td_rnn_run_layers_state(const td_rnn_config *cfg, const void *packed, const td_diffusion_config *dcfg, const float *z,
-                            const uint8_t *idx, int batch, int L, void *workspace, hipStream_t stream, const char **last_act);
-int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
-                const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
+int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,
+                   const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, const float *film, int film_rows,
+                   const int32_t *film_row, int batch, int L, float *y, void *workspace, hipStream_t stream, bool chain);
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
                            const int32_t *t_dev, const float *noise, const float *uniforms, size_t noise_stride,
                            size_t uni_stride, td_rng rng, hipStream_t stream);
@@ -103,11 +100,9 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
 
     auto enqueue_step = [&]() -> int {
         int r;
-        const char *act = nullptr;
-        // denoiser input (mixed_diffusion.py:439) and its layer-0 fragment packing in one pass
-        r = td_rnn_run_layers_state(rnn, packed, cfg, z, idx, batch, L, rnn_ws, stream, &act);
-        if (r != TD_OK) return r;
-        r = td_rnn_head(rnn, misc, act, film_table, T, counter, batch, L, mo, stream);
+        // denoiser input (mixed_diffusion.py:439) and its layer-0 fragment packing in one pass, the layers, the head
+        // (fused into the top layer's kernel where the batch-block family runs it)
+        r = td_rnn_denoise(rnn, packed, misc, nullptr, cfg, z, idx, film_table, T, counter, batch, L, mo, rnn_ws, stream, true);
         if (r != TD_OK) return r;
         r = td_launch_reverse_step(cfg, batch, mo, z, idx, 0, counter, noise, uniforms, noise ? nstride : 0,
                                    uniforms ? ustride : 0, rng, stream);

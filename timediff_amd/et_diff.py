@@ -22,6 +22,7 @@ import os
 import sys
 import timeit
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch.utils.data import DataLoader
@@ -239,10 +240,102 @@ class ETDiff(nn.Module):
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
 
-    def save_weights(self):
-        weights = {"diff_step": self.step, "diff_model": self.model.state_dict(), "opt": self._opt_state_dict(),
-                   "ema": self.ema.state_dict(), "scaler": None}
-        torch.save(weights, self.check_point_path)
+    def save_weights(self, block=True):
+        """The reference's checkpoint dict (et_diff.py:208-216), written without stalling the training loop: the device
+        state is snapshotted in stream order (four device-to-device copies of the flat weight / EMA / Adam buffers plus
+        the few registered buffers), copied to pinned host memory on a side stream, and a writer thread builds the
+        dict, serialises it to a temporary file and renames it into place.  block=True (the default, what the
+        reference's synchronous torch.save gives a caller) returns once the file is there; the training loop passes
+        block=False and joins the writer before the next checkpoint and at the end of training."""
+        import threading
+        self.wait_for_checkpoint()
+        dev = torch.cuda.current_stream()
+        flat = {"param": self.flat_param, "ema": self.flat_ema, "m": self.exp_avg, "v": self.exp_avg_sq}
+        snap = {k: v.detach().clone() for k, v in flat.items()}
+
+        def layout(module, flat_t):
+            """state_dict entries in order: ("flat", offset, shape) for views into the flat buffer, ("own", clone) otherwise"""
+            lo, hi = flat_t.data_ptr(), flat_t.data_ptr() + flat_t.numel() * 4
+            out = []
+            for name, t in module.state_dict().items():
+                if t.is_cuda and t.dtype == torch.float32 and lo <= t.data_ptr() < hi:
+                    out.append((name, "flat", (t.data_ptr() - lo) // 4, tuple(t.shape)))
+                else:
+                    out.append((name, "own", t.detach().clone(), None))
+            return out
+        plan_model, plan_ema = layout(self.model, self.flat_param), layout(self.ema, self.flat_ema)
+        ready = torch.cuda.Event()
+        ready.record(dev)
+        if getattr(self, "_ckpt_stream", None) is None:
+            self._ckpt_stream = torch.cuda.Stream(device=self._device)
+            self._ckpt_host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in snap.items()}
+            self._ckpt_small = {}       # pinned copies of the registered buffers, by (which dict, name)
+        with torch.cuda.stream(self._ckpt_stream):
+            self._ckpt_stream.wait_event(ready)
+            for k, v in snap.items():
+                self._ckpt_host[k].copy_(v, non_blocking=True)
+                v.record_stream(self._ckpt_stream)
+            for which, plan in enumerate((plan_model, plan_ema)):
+                for i, (name, kind, a, b) in enumerate(plan):
+                    if kind == "own":
+                        h = a
+                        if a.is_cuda:
+                            h = self._ckpt_small.get((which, name))
+                            if h is None or h.shape != a.shape or h.dtype != a.dtype:
+                                h = self._ckpt_small[(which, name)] = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
+                            h.copy_(a, non_blocking=True)
+                            a.record_stream(self._ckpt_stream)
+                        plan[i] = (name, "host", h, None)
+            done = torch.cuda.Event()
+            done.record(self._ckpt_stream)
+        meta = dict(step=self.step, opt_step=self.opt_step, lr=self.lr, betas=tuple(self.betas), eps=self.eps,
+                    shapes=[tuple(p.shape) for p in self.params], path=self.check_point_path)
+        host = self._ckpt_host
+
+        def build(plan, flat_h):
+            from collections import OrderedDict
+            return OrderedDict((name, flat_h[a:a + int(np.prod(b, dtype=np.int64))].view(b).clone() if kind == "flat" else a.clone())
+                               for name, kind, a, b in plan)
+
+        def write():
+            done.synchronize()
+            state, off = {}, 0
+            for i, shape in enumerate(meta["shapes"]):
+                n = int(np.prod(shape, dtype=np.int64))
+                state[i] = {"step": torch.tensor(float(meta["opt_step"])), "exp_avg": host["m"][off:off + n].view(shape).clone(),
+                            "exp_avg_sq": host["v"][off:off + n].view(shape).clone()}
+                off += n
+            group = {"lr": meta["lr"], "betas": meta["betas"], "eps": meta["eps"], "weight_decay": 0, "amsgrad": False,
+                     "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                     "params": list(range(len(meta["shapes"])))}
+            weights = {"diff_step": meta["step"], "diff_model": build(plan_model, host["param"]),
+                       "opt": {"state": state if meta["opt_step"] > 0 else {}, "param_groups": [group]},
+                       "ema": build(plan_ema, host["ema"]), "scaler": None}
+            tmp = meta["path"] + ".tmp"
+            torch.save(weights, tmp)
+            os.replace(tmp, meta["path"])
+
+        self._ckpt_error = None
+
+        def guarded():
+            try:
+                write()
+            except BaseException as e:      # surfaces in wait_for_checkpoint
+                self._ckpt_error = e
+        self._ckpt_thread = threading.Thread(target=guarded, name="timediff-checkpoint", daemon=False)
+        self._ckpt_thread.start()
+        if block:
+            self.wait_for_checkpoint()
+
+    def wait_for_checkpoint(self):
+        """Joins the checkpoint writer, if one is in flight, and re-raises what it raised."""
+        th = getattr(self, "_ckpt_thread", None)
+        if th is not None:
+            th.join()
+            self._ckpt_thread = None
+            if self._ckpt_error is not None:
+                err, self._ckpt_error = self._ckpt_error, None
+                raise err
 
     def load(self, path):
         # the checkpoint dict holds tensors, dicts, lists, tuples, numbers and None only (et_diff.py:208-216): the
@@ -342,7 +435,7 @@ class ETDiff(nn.Module):
                     self.wandb.log({"total_loss": total_loss})
                     last_log = self.timer()
                 if self.is_main_process and self.step != 0 and self.step % self.sample_every == 0:
-                    self.save_weights()
+                    self.save_weights(block=False)      # the writer runs beside the next steps
                 pbar.update(1)
         if self.is_main_process:
             self.save_weights()
