@@ -85,6 +85,13 @@ TD_API int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const *lay
  * scale = film[:, :D*H], shift = film[:, D*H:].  temb_out (n_t, time_dim) may be NULL. */
 TD_API int td_rnn_time_film(const td_rnn_config *cfg, const float *const *misc_host, const int64_t *t, int32_t n_t,
                      float *film, float *temb_out, void *stream);
+/* Backward of td_rnn_time_film (autograd through blocks.py:324-329, :285 as run by accelerator.backward, et_diff.py:237):
+ * given grad_film (n_t, 2*D*H), ACCUMULATES the gradients of the six time-embedding / FiLM parameters into
+ * grad_misc[TD_TE_W1 .. TD_FILM_B] (same table layout as misc_host; the other entries are not touched).  The forward
+ * values are recomputed from t.  workspace: td_rnn_time_film_backward_workspace_bytes(cfg, n_t) bytes. */
+TD_API size_t td_rnn_time_film_backward_workspace_bytes(const td_rnn_config *cfg, int32_t n_t);
+TD_API int td_rnn_time_film_backward(const td_rnn_config *cfg, const float *const *misc_host, const int64_t *t, int32_t n_t,
+                              const float *grad_film, float *const *grad_misc_host, void *workspace, void *stream);
 
 /* blocks.py:333-341 after the time embedding: y = fc(FiLM(LayerNorm(BRNN(x^T))))^T.
  *   x: (B, c_in, L) fp32    y: (B, c_out, L) fp32

@@ -490,3 +490,58 @@ def test_vector_and_scalar_kernels_agree(dev):
     assert torch.equal(i0, i1)
     assert torch.allclose(z0, z1, rtol=1e-6, atol=1e-6) and torch.allclose(g0, g1, rtol=1e-5, atol=1e-9)
     assert abs(l0.item() - l1.item()) <= 1e-6 * abs(l0.item())
+
+
+def random_state_small(seed, H=32, C=7, dirs=2):
+    """A one-layer LSTM denoiser state dict with random (non-zero) time-embedding / FiLM parameters."""
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / np.sqrt(H)
+    sd = {}
+    for sfx in ("", "_reverse")[:dirs]:
+        sd[f"rnn.rnn.weight_ih_l0{sfx}"] = (torch.rand(4 * H, C, generator=g) * 2 - 1) * k
+        sd[f"rnn.rnn.weight_hh_l0{sfx}"] = (torch.rand(4 * H, H, generator=g) * 2 - 1) * k
+        sd[f"rnn.rnn.bias_ih_l0{sfx}"] = (torch.rand(4 * H, generator=g) * 2 - 1) * k
+        sd[f"rnn.rnn.bias_hh_l0{sfx}"] = (torch.rand(4 * H, generator=g) * 2 - 1) * k
+    DH = dirs * H
+    sd["time_emb.1.weight"] = torch.randn(256, 64, generator=g) / 8; sd["time_emb.1.bias"] = 0.1 * torch.randn(256, generator=g)
+    sd["time_emb.3.weight"] = torch.randn(256, 256, generator=g) / 16; sd["time_emb.3.bias"] = 0.1 * torch.randn(256, generator=g)
+    sd["rnn.time_mlp.1.weight"] = torch.randn(2 * DH, 256, generator=g) / 16; sd["rnn.time_mlp.1.bias"] = 0.1 * torch.randn(2 * DH, generator=g)
+    sd["rnn.norm.weight"] = 1 + 0.1 * torch.randn(DH, generator=g); sd["rnn.norm.bias"] = 0.1 * torch.randn(DH, generator=g)
+    sd["fc.weight"] = torch.randn(C, DH, generator=g) / np.sqrt(DH); sd["fc.bias"] = 0.1 * torch.randn(C, generator=g)
+    return {k_: v.numpy() for k_, v in sd.items()}
+
+
+@pytest.mark.parametrize("n", [1, 37, 600])
+def test_time_film_backward_against_torch(n, dev):
+    """td_rnn_time_film_backward (time-embedding MLP + FiLM linear, blocks.py:12-24, :324-329, :285) against torch
+    autograd through the same fp32 arithmetic on the CPU (a floating-point kernel: fp32 torch is the reference here);
+    forward against the same composition."""
+    import math
+    sd = random_state_small(seed=n)
+    den = den_kernels(sd, dev)
+    g = torch.Generator().manual_seed(n)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    DH2 = sd["rnn.time_mlp.1.weight"].shape[0]
+    gf = torch.randn(n, DH2, generator=g) / n
+    P = {k: torch.from_numpy(np.asarray(sd[k])).clone().requires_grad_(True) for k in
+         ("time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_emb.3.bias", "rnn.time_mlp.1.weight", "rnn.time_mlp.1.bias")}
+    half = P["time_emb.1.weight"].shape[1] // 2
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    e = t[:, None].float() * freq[None]
+    e = torch.cat([e.sin(), e.cos()], -1)
+    h = torch.nn.functional.gelu(e @ P["time_emb.1.weight"].T + P["time_emb.1.bias"])
+    temb = h @ P["time_emb.3.weight"].T + P["time_emb.3.bias"]
+    film = torch.nn.functional.silu(temb) @ P["rnn.time_mlp.1.weight"].T + P["rnn.time_mlp.1.bias"]
+    film.backward(gf)
+    got_film = den.time_film(t.to(dev)).cpu()
+    assert torch.allclose(got_film, film.detach(), rtol=1e-4, atol=3e-5)
+    got = den.time_film_backward(t.to(dev), gf.to(dev))
+    for k, p in P.items():
+        ref = p.grad.numpy()
+        err = np.abs(got[k].cpu().numpy() - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-7, (k, err, np.abs(ref).max())
+    # accumulation into a sink
+    sink = {k: torch.ones_like(v) for k, v in got.items()}
+    den.time_film_backward(t.to(dev), gf.to(dev), sink=sink)
+    for k in got:
+        assert torch.allclose(sink[k], got[k] + 1, rtol=1e-5, atol=1e-6)

@@ -57,6 +57,8 @@ _SIGS = {
     "td_rnn_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
     "td_rnn_pack_weights": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _P]),
     "td_rnn_time_film": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _I, _P, _P, _P]),
+    "td_rnn_time_film_backward_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I]),
+    "td_rnn_time_film_backward": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _I, _P, C.POINTER(_P), _P, _P]),
     "td_rnn_forward": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "td_rnn_read_hidden": (C.c_int, [C.POINTER(RnnConfig), _P, _I, _I, _P, _P]),
     "td_rnn_train_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),

@@ -1,6 +1,6 @@
-"""Autograd wiring of the denoiser: the recurrent stack, LayerNorm/FiLM head and fc run forward and
-backward in the HIP library; only the time-embedding MLP (three (B, 256)-sized linears, blocks.py:324-329
-and :285) is left to torch's own autograd during training."""
+"""Autograd wiring of the denoiser: ONE autograd node whose forward and backward run entirely in the HIP library --
+the time-embedding MLP + FiLM linear (td_rnn_time_film / td_rnn_time_film_backward), the recurrent stack, the
+LayerNorm/FiLM head and fc (td_rnn_forward_train / td_rnn_backward).  No stock torch op is on the training path."""
 import torch
 
 from . import _lib
@@ -8,16 +8,17 @@ from . import _lib
 
 class _DenoiserFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, x, film, *params):
+    def forward(ctx, module, x, time, *params):
         k = module.kernels()
+        film = k.time_film(time)
         y = k.forward_train(x, film)
         ctx.module = module
-        ctx.save_for_backward(film)
+        ctx.save_for_backward(film, time)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        (film,) = ctx.saved_tensors
+        film, time = ctx.saved_tensors
         k = ctx.module.kernels()
         sink = getattr(ctx.module, "_grad_sink", None)
         if sink is not None:
@@ -25,22 +26,22 @@ class _DenoiserFn(torch.autograd.Function):
             # AccumulateGrad pass), and the trainer may start a layer's all-reduce while the layers below are
             # still being differentiated (et_diff.py: ETDiff._layer_reduce)
             _, _, g_film = k.backward(grad_y.contiguous(), film, sink=sink["tensors"], on_layer_done=sink.get("on_layer_done"))
-            return (None, None, g_film) + (None,) * (len(k._lkeys) + len(_lib.MISC_KEYS[6:]))
+            k.time_film_backward(time, g_film, sink=sink["tensors"])
+            return (None, None, None) + (None,) * (len(k._lkeys) + len(_lib.MISC_KEYS))
         g_layer, g_misc, g_film = k.backward(grad_y.contiguous(), film)
-        tail = [g_misc[key] for key in _lib.MISC_KEYS[6:]]
-        return (None, None, g_film, *g_layer, *tail)
+        g_misc.update(k.time_film_backward(time, g_film))
+        return (None, None, None, *g_layer, *[g_misc[key] for key in _lib.MISC_KEYS])
 
 
 def _train_params(module):
     k = module.kernels()
     named = dict(module.named_parameters())
-    return [named[key] for key in k._lkeys] + [named[key] for key in _lib.MISC_KEYS[6:]]
+    return [named[key] for key in k._lkeys] + [named[key] for key in _lib.MISC_KEYS]
 
 
 def denoiser_apply(module, x, time):
     """RNN.forward (blocks.py:333-341)."""
     params = _train_params(module) if torch.is_grad_enabled() else None
     if params is not None and any(p.requires_grad for p in module.parameters()):
-        film = module.rnn.time_mlp(module.time_emb(time))          # torch autograd: tiny (B, 256) linears
-        return _DenoiserFn.apply(module, x, film, *params)
+        return _DenoiserFn.apply(module, x, time, *params)
     return module.kernels().forward(x, time)

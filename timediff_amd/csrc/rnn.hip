@@ -271,6 +271,122 @@ extern "C" int td_rnn_time_film(const td_rnn_config *cfg, const float *const *mi
     return TD_OK;
 }
 
+// Backward of the same path (autograd through blocks.py:324-329 and :285), given d film (n_t, 2 D H).  Stage 1, one block
+// per row of t: recompute the forward values (cheaper than saving them), back-propagate the activations, leave per
+// row the vectors the weight gradients are outer products of, add the bias gradients.  Stage 2: every weight gradient is
+// a sum over the rows of an outer product; one thread per weight element walks the rows.
+struct TdFilmBwdParams {
+    const float *w1, *b1, *w2, *b2, *wf, *bf;
+    const int64_t *t;
+    const float *gfilm;
+    float *rows;                       // per row: [sinus (E) | a1 (T) | s (T) | d v1 (T) | d v2 (T)]
+    float *d_w1, *d_b1, *d_w2, *d_b2, *d_wf, *d_bf;   // accumulated
+    int embed_dim, time_dim, film_dim, n_t;
+};
+
+__global__ __launch_bounds__(256) void td_time_film_bwd_rows_kernel(TdFilmBwdParams p) {
+    __shared__ float sinus[1024], v1[1024], a1[1024], v2[1024], tmp[1024];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int E = p.embed_dim, T = p.time_dim, F = p.film_dim;
+    const float tv = (float)p.t[i];
+    const int half = E / 2;
+    const float emb = (float)(-(9.210340371976184 / (double)(half - 1)));
+    for (int j = tid; j < half; j += 256) {
+        const float a = tv * expf((float)j * emb);
+        sinus[j] = sinf(a);
+        sinus[half + j] = cosf(a);
+    }
+    __syncthreads();
+    for (int r = tid; r < T; r += 256) {
+        float v = p.b1[r];
+        const float *w = p.w1 + (size_t)r * E;
+        for (int k = 0; k < E; ++k) v = fmaf(w[k], sinus[k], v);
+        v1[r] = v;
+        a1[r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    }
+    __syncthreads();
+    for (int r = tid; r < T; r += 256) {
+        float v = p.b2[r];
+        const float *w = p.w2 + (size_t)r * T;
+        for (int k = 0; k < T; ++k) v = fmaf(w[k], a1[k], v);
+        v2[r] = v;
+    }
+    __syncthreads();
+    const float *gf = p.gfilm + (size_t)i * F;
+    float *row = p.rows + (size_t)i * (E + 4 * T);
+    // d s = W_f^T d film ; d v2 = d s * silu'(v2)
+    for (int k = tid; k < T; k += 256) {
+        float ds = 0.f;
+        for (int r = 0; r < F; ++r) ds = fmaf(p.wf[(size_t)r * T + k], gf[r], ds);
+        const float v = v2[k], sg = 1.0f / (1.0f + expf(-v));
+        const float dv = ds * sg * (1.0f + v * (1.0f - sg));
+        tmp[k] = dv;
+        row[E + T + k] = v * sg;          // s = silu(v2)
+        row[E + 3 * T + k] = dv;
+        atomicAdd(&p.d_b2[k], dv);
+    }
+    for (int r = tid; r < F; r += 256) atomicAdd(&p.d_bf[r], gf[r]);
+    __syncthreads();
+    // d a1 = W_2^T d v2 ; d v1 = d a1 * gelu'(v1)
+    for (int k = tid; k < T; k += 256) {
+        float da = 0.f;
+        for (int r = 0; r < T; ++r) da = fmaf(p.w2[(size_t)r * T + k], tmp[r], da);
+        const float v = v1[k];
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f)), pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+        const float dv = da * (cdf + v * pdf);
+        row[E + k] = a1[k];
+        row[E + 2 * T + k] = dv;
+        atomicAdd(&p.d_b1[k], dv);
+    }
+    for (int k = tid; k < E; k += 256) row[k] = sinus[k];
+}
+
+// d W[r][k] += sum_i left[i][r] * right[i][k]   (left / right: columns of the per-row records, or d film)
+__global__ __launch_bounds__(256) void td_outer_sum_kernel(const float *__restrict__ left, size_t lstride, const float *__restrict__ right,
+                                                            size_t rstride, float *__restrict__ dw, int R, int K, int n) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)R * K) return;
+    const int r = (int)(idx / K), k = (int)(idx % K);
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc = fmaf(left[(size_t)i * lstride + r], right[(size_t)i * rstride + k], acc);
+    dw[idx] += acc;
+}
+
+extern "C" size_t td_rnn_time_film_backward_workspace_bytes(const td_rnn_config *cfg, int32_t n_t) {
+    if (!cfg || n_t <= 0) return 0;
+    return (size_t)n_t * (cfg->embed_dim + 4 * cfg->time_dim) * sizeof(float);
+}
+
+extern "C" int td_rnn_time_film_backward(const td_rnn_config *cfg, const float *const *misc, const int64_t *t, int32_t n_t,
+                                         const float *grad_film, float *const *grad_misc, void *workspace, void *stream_) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    TD_REQUIRE(misc && t && grad_film && grad_misc && workspace && n_t > 0, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    TdFilmBwdParams p;
+    p.w1 = misc[TD_TE_W1]; p.b1 = misc[TD_TE_B1]; p.w2 = misc[TD_TE_W2]; p.b2 = misc[TD_TE_B2];
+    p.wf = misc[TD_FILM_W]; p.bf = misc[TD_FILM_B];
+    p.t = t; p.gfilm = grad_film; p.rows = (float *)workspace;
+    p.d_w1 = grad_misc[TD_TE_W1]; p.d_b1 = grad_misc[TD_TE_B1]; p.d_w2 = grad_misc[TD_TE_W2]; p.d_b2 = grad_misc[TD_TE_B2];
+    p.d_wf = grad_misc[TD_FILM_W]; p.d_bf = grad_misc[TD_FILM_B];
+    TD_REQUIRE(p.d_w1 && p.d_b1 && p.d_w2 && p.d_b2 && p.d_wf && p.d_bf, "NULL gradient pointer for the time-embedding parameters");
+    const int E = cfg->embed_dim, T = cfg->time_dim, F = 2 * cfg->dirs * cfg->hidden;
+    p.embed_dim = E; p.time_dim = T; p.film_dim = F; p.n_t = n_t;
+    hipLaunchKernelGGL(td_time_film_bwd_rows_kernel, dim3(n_t), dim3(256), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    const size_t rs = (size_t)E + 4 * T;
+    const float *rows = p.rows;
+    // d W_f = d film^T s ; d W_2 = d v2^T a1 ; d W_1 = d v1^T sinus
+    hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(F * T, 256)), dim3(256), 0, stream, grad_film, (size_t)F, rows + E + T, rs, p.d_wf, F, T, n_t);
+    TD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(T * T, 256)), dim3(256), 0, stream, rows + E + 3 * T, rs, rows + E, rs, p.d_w2, T, T, n_t);
+    TD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(T * E, 256)), dim3(256), 0, stream, rows + E + 2 * T, rs, rows, rs, p.d_w1, T, E, n_t);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // layer-0 input: (B, C, L) fp32 -> B-operand fragments, split into bf16 hi + lo parts so the first
 // input projection keeps ~16 mantissa bits (the one-hot logs are {0, -69.0776}; plain bf16 would

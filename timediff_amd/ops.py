@@ -77,6 +77,24 @@ class DenoiserKernels:
         check(lib().td_rnn_time_film(C.byref(self.cfg), self._misc_tab, ptr(t), n, ptr(film), ptr(temb), _stream()))
         return (film, temb) if want_temb else film
 
+    def time_film_backward(self, t, grad_film, sink=None):
+        """Backward of time_film (the time-embedding MLP + FiLM linear, blocks.py:324-329 and :285): d film (n, 2DH) ->
+        {misc key: grad} of the six parameters; sink: tensors to ACCUMULATE into instead (the trainer's flat buffer)."""
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        grad_film = _f32(grad_film)
+        n = t.numel()
+        keys = _lib.MISC_KEYS[:6]
+        if sink is None:
+            g = {k: torch.zeros_like(self._misc[i]) for i, k in enumerate(keys)}
+        else:
+            g = {k: sink[k] for k in keys}
+            for i, k in enumerate(keys):
+                assert g[k].dtype == torch.float32 and g[k].is_contiguous() and g[k].shape == self._misc[i].shape
+        tab = (C.c_void_p * _lib.TD_MISC_COUNT)(*[g[k].data_ptr() if k in g else None for k in _lib.MISC_KEYS])
+        ws = torch.empty(lib().td_rnn_time_film_backward_workspace_bytes(C.byref(self.cfg), n), dtype=torch.uint8, device=self.device)
+        check(lib().td_rnn_time_film_backward(C.byref(self.cfg), self._misc_tab, ptr(t), n, ptr(grad_film), tab, ptr(ws), _stream()))
+        return g
+
     def workspace(self, batch, seq_len):
         need = lib().td_rnn_workspace_bytes(C.byref(self.cfg), batch, seq_len)
         if self._ws is None or self._ws.numel() < need:
