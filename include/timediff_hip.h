@@ -168,6 +168,9 @@ typedef struct td_diffusion_config {
     int32_t num_index[TD_MAX_CAT * 2]; /* numerical_features_indices (dataset channel)    */
     int32_t cat_index[TD_MAX_CAT];   /* categorical_features_indices (dataset channel)    */
     int32_t data_channels;       /* channels of a dataset tensor / of sample()'s result   */
+    int32_t raw_range;           /* 0: auto_normalize=True, the continuous channels are mapped [0, 1] -> [-1, 1] on the way
+                                    in and back on the way out (mixed_diffusion.py:160-162); 1: auto_normalize=False, identity.
+                                    (Occupies what was padding in front of the pointer: zero-initialised configs keep meaning 0.) */
     const float *tables;         /* device, (TD_TAB_COUNT, T)                             */
 } td_diffusion_config;
 
@@ -266,6 +269,22 @@ TD_API int td_grad_norm(const float *grad, size_t n, float *norm, void *workspac
 TD_API int td_clip_adam_ema(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, size_t n,
                      const float *norm, float max_norm, float lr, float beta1, float beta2, float eps, int32_t step,
                      int32_t ema_mode, float ema_decay, void *stream);
+
+/* ---- TSTR classifier: the nearest downstream consumer of the same recurrent kernels --------------------------------
+ * evaluate/nn_classifier.py:89-127 (class RNN: bidirectional nn.LSTM / nn.GRU over (B, C, L), final hidden state of each
+ * direction -> Linear(2H, 1) -> Sigmoid) and :140-165 (training with F.binary_cross_entropy).  cfg: c_in = channels,
+ * hidden, layers, dirs, gru as for the denoiser (c_out, embed_dim, time_dim are not used: any valid values); weights are
+ * packed with td_rnn_pack_weights / td_rnn_pack_weights_T.
+ *   td_cls_forward: x (B, c_in, L) -> prob (B); keeps in `workspace` (td_cls_workspace_bytes) what the backward needs.
+ *   td_cls_backward: gradient w.r.t. every parameter of mean BCE(prob, y) (y given), or of a loss whose gradient w.r.t.
+ *     prob is grad_prob (y NULL), ACCUMULATED into grad_layer (4 pointers per (layer, direction): w_ih, w_hh, b_ih, b_hh in
+ *     torch layout), grad_w (D*H) and grad_b (1). */
+TD_API size_t td_cls_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
+TD_API int td_cls_forward(const td_rnn_config *cfg, const void *packed, const float *x, const float *w, const float *b,
+                   int32_t batch, int32_t seq_len, float *prob, void *workspace, void *stream);
+TD_API int td_cls_backward(const td_rnn_config *cfg, const void *packT, const float *w, const float *prob, const float *y,
+                    const float *grad_prob, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer,
+                    float *grad_w, float *grad_b, void *stream);
 
 /* Kernel-selection knobs for tests and measurements, no counterpart in the reference (process-wide, not
  * thread-safe against concurrent launches).

@@ -545,3 +545,47 @@ def test_time_film_backward_against_torch(n, dev):
     den.time_film_backward(t.to(dev), gf.to(dev), sink=sink)
     for k in got:
         assert torch.allclose(sink[k], got[k] + 1, rtol=1e-5, atol=1e-6)
+
+
+def test_auto_normalize_false(dev):
+    """MixedDiffusion(auto_normalize=False) (mixed_diffusion.py:160-162: normalize / unnormalize are the identity): the
+    forward noising uses the continuous channels as given and leaves the caller's batch alone, the sampler returns z
+    itself instead of (z + 1) / 2; everything else is the auto_normalize=True arithmetic."""
+    from timediff_amd.ops import DiffusionKernels
+    L, T, B = 8, 20, 5
+    num, cat, K = [0, 2], [1], [3]
+    tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
+    raw = DiffusionKernels(num, cat, K, L, T, tables, 3, dev, auto_normalize=False)
+    std = DiffusionKernels(num, cat, K, L, T, tables, 3, dev)
+    rng = np.random.default_rng(0)
+    data = rng.random((B, 3, L)).astype(np.float32)
+    data[:, 1] = rng.integers(0, 3, (B, L))
+    t = rng.integers(0, T, B)
+    noise = rng.standard_normal((B, 2, L)).astype(np.float32)
+    uni = rng.random((B, 3, L)).astype(np.float32)
+    shifted = data.copy()
+    shifted[:, num] = (data[:, num] + 1) / 2            # normalising this gives `data` back
+    a = raw.q_sample(cu(data, dev), cu(t, dev), cu(noise, dev), cu(uni, dev))
+    b = std.q_sample(cu(shifted, dev), cu(t, dev), cu(noise, dev), cu(uni, dev))
+    for x, y in zip(a, b):
+        if x is not None:
+            assert torch.allclose(x.float(), y.float(), rtol=0, atol=2e-6)
+    z = cu(rng.standard_normal((B, 2, L)).astype(np.float32), dev)
+    idx = cu(rng.integers(0, 3, (B, 1, L)).astype(np.uint8), dev)
+    s_raw, s_std = raw.decode(z, idx).cpu().numpy(), std.decode(z, idx).cpu().numpy()
+    np.testing.assert_array_equal(s_raw[:, num], z.cpu().numpy())
+    np.testing.assert_allclose(s_std[:, num], (z.cpu().numpy() + 1) / 2, rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(s_raw[:, cat], s_std[:, cat])
+    # module level: constructor accepts the flag and the caller's batch is not rewritten
+    from models.ETDiff.blocks import RNN
+    from models.ETDiff.mixed_diffusion import MixedDiffusion
+    rnn = RNN(input_channels=4, hidden_channels=32, output_channels=4, layers=1, model="lstm", bidirectional=True)
+    diff = MixedDiffusion(rnn, seq_length=L, channels=4, numerical_features_indices=num, categorical_features_indices=cat,
+                          categorical_num_classes=[2], timesteps=T, auto_normalize=False).to(dev)
+    data[:, 1] = data[:, 1] > 1
+    batch = torch.from_numpy(data).to(dev)
+    keep = batch.clone()
+    loss = diff(batch)
+    assert torch.isfinite(loss) and torch.equal(batch, keep)
+    out = diff.sample(batch_size=4)
+    assert out.shape == (4, 3, L) and torch.isfinite(out).all()

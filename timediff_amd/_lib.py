@@ -32,7 +32,8 @@ class RnnConfig(C.Structure):
 class DiffusionConfig(C.Structure):
     _fields_ = [("n_num", C.c_int32), ("n_cat", C.c_int32), ("seq_len", C.c_int32), ("timesteps", C.c_int32),
                 ("num_classes", C.c_int32 * TD_MAX_CAT), ("num_index", C.c_int32 * (2 * TD_MAX_CAT)),
-                ("cat_index", C.c_int32 * TD_MAX_CAT), ("data_channels", C.c_int32), ("tables", C.c_void_p)]
+                ("cat_index", C.c_int32 * TD_MAX_CAT), ("data_channels", C.c_int32), ("raw_range", C.c_int32),
+                ("tables", C.c_void_p)]
 
 
 class Rng(C.Structure):
@@ -88,6 +89,9 @@ _SIGS = {
                                    C.c_float, _I, _I, C.c_float, _P]),
     "td_set_layer_kernel": (C.c_int, [_I]),
     "td_rnn_layer_kernel_choice": (C.c_int, [C.POINTER(RnnConfig), _I, _I]),
+    "td_cls_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
+    "td_cls_forward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "td_cls_backward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(_P), _P, _P, _P]),
     "td_set_dw_gemm": (C.c_int, [_I]),
     "td_set_head_fusion": (C.c_int, [_I]),
     "td_profile_enable": (C.c_int, [_I]),

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void td_q_sample_kernel(td_diffusion_config c,
             const TdVec<VEC> eps = draw.normal(ch);
             TdVec<VEC> o;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o.v[e] = sa * (d.v[e] * 2.0f - 1.0f) + s1 * eps.v[e];  // :189-194, :240-248
+            for (int e = 0; e < VEC; ++e) o.v[e] = sa * (c.raw_range ? d.v[e] : d.v[e] * 2.0f - 1.0f) + s1 * eps.v[e];  // :189-194, :240-248
             td_stf<VEC>(x_in + ((size_t)b * C_io + ch) * L + l0, o);
             if (noise_out) td_stf<VEC>(noise_out + ((size_t)b * c.n_num + ch) * L + l0, eps);
         }
@@ -796,7 +796,10 @@ __global__ __launch_bounds__(256) void td_decode_kernel(td_diffusion_config c, i
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / L), l = (int)(i % L);
         for (int ch = 0; ch < c.n_num; ++ch)
-            samples[((size_t)b * c.data_channels + c.num_index[ch]) * L + l] = (z[((size_t)b * c.n_num + ch) * L + l] + 1.0f) * 0.5f;
+        {
+            const float zv = z[((size_t)b * c.n_num + ch) * L + l];
+            samples[((size_t)b * c.data_channels + c.num_index[ch]) * L + l] = c.raw_range ? zv : (zv + 1.0f) * 0.5f;   // :449
+        }
         for (int v = 0; v < c.n_cat; ++v)
             samples[((size_t)b * c.data_channels + c.cat_index[v]) * L + l] = (float)idx[((size_t)b * c.n_cat + v) * L + l];
     }

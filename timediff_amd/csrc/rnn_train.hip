@@ -799,72 +799,14 @@ __global__ __launch_bounds__(256) void td_bias_reduce_kernel(const __bf16 *A, si
 // ---------------------------------------------------------------------------------------------
 // backward entry point
 // ---------------------------------------------------------------------------------------------
-extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
-                               const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
-                               float *const *grad_layer, float *const *grad_misc, float *grad_film, void *stream_) {
-    return td_rnn_backward_cb(cfg, packT, misc, film, grad_y, batch, seq_len, workspace, grad_layer, grad_misc, grad_film,
-                              nullptr, nullptr, stream_);
-}
-
-extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
-                                  const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
-                                  float *const *grad_layer, float *const *grad_misc, float *grad_film,
-                                  td_layer_done_fn layer_done, void *user, void *stream_) {
-    TD_REQUIRE(cfg && packT && misc && film && grad_y && workspace && grad_layer && grad_misc && grad_film, "NULL argument");
-    TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
-    TdRnnGeom g;
-    int rc = td_rnn_geom(cfg, &g);
-    if (rc != TD_OK) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
-    const int L = seq_len, N = cfg->layers, D = g.dirs, H = cfg->hidden, G = cfg->gru ? 3 : 4;
+// The recurrent layers' part of the backward pass, top down: the gradient w.r.t. the top layer's output is in gout[N-1][0]
+// (fragments) when this is called -- written by the denoiser's head backward, or by the classifier's (td_cls_backward).
+static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, const void *packT, int batch, int L, char *ws,
+                              float *const *grad_layer, td_layer_done_fn layer_done, void *user, hipStream_t stream) {
+    const int N = cfg->layers, D = g.dirs, H = cfg->hidden, G = cfg->gru ? 3 : 4, DH = D * H;
     const TdTrainLayout t = td_train_layout(cfg, g, batch, L);
     const TdPackTGeom tg = td_packT_geom(cfg, g);
-    char *ws = (char *)workspace;
-    const int DH = D * H;
-
-    // ---- head --------------------------------------------------------------------------------
-    TD_HIP(hipMemsetAsync(grad_film, 0, (size_t)batch * 2 * DH * sizeof(float), stream));
-    {
-        TdHeadBwdParams p;
-        p.act = ws + t.act[N - 1];
-        p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.film = film; p.gy = grad_y;
-        p.gout = ws + t.gout[N - 1][0];
-        p.chan = (float *)(ws + t.chan); p.g1 = (float *)(ws + t.g1);
-        p.d_film = grad_film; p.d_ln_w = grad_misc[TD_LN_W]; p.d_ln_b = grad_misc[TD_LN_B];
-        p.d_fc_w = grad_misc[TD_FC_W]; p.d_fc_b = grad_misc[TD_FC_B];
-        TD_REQUIRE(p.d_ln_w && p.d_ln_b && p.d_fc_w && p.d_fc_b, "NULL gradient pointer for the head parameters");
-        p.B = batch; p.L = L; p.nbb = t.nbb; p.H = H; p.hpad = g.hpad; p.kh = g.kh; p.dirs = D; p.c_out = cfg->c_out;
-        const size_t ntask = (size_t)L * t.nbb;
-        int blocks = (int)((ntask + 3) / 4);
-        if (blocks > 2048) blocks = 2048;
-        const int DHP = D * g.hpad;
-        const size_t lds_max = 160 * 1024;
-        auto launch = [&](auto kern, size_t shm) -> int {
-            if (shm) TD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, stream, p);
-            TD_LAUNCH_CHECK();
-            return TD_OK;
-        };
-        const int cm = cfg->c_out <= 16 ? 16 : 32;
-        const size_t shm = (size_t)(1 + cm) * DHP * sizeof(float);
-        if (shm <= lds_max) rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, false>, shm) : launch(td_head_bwd_dh_kernel<32, false>, shm);
-        else rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, true>, 0) : launch(td_head_bwd_dh_kernel<32, true>, 0);
-        if (rc != TD_OK) return rc;
-        const int rows = batch * cfg->c_out;
-        hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, stream, grad_y, p.g1, rows, L);
-        TD_LAUNCH_CHECK();
-        // about 2048 waves per launch, chunks of at least 16 steps
-        p.lch = 2048 / (t.nbb * D * g.kh);
-        if (p.lch > L / 16) p.lch = L / 16;
-        if (p.lch < 1) p.lch = 1;
-        p.llen = td_cdiv(L, p.lch);
-        p.lch = td_cdiv(L, p.llen);
-        hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16) * p.lch), dim3(256), 0,
-                           stream, p);
-        TD_LAUNCH_CHECK();
-    }
-    if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
-
+    int rc = TD_OK;
     float *dwpart = t.cols >= 2 * TD_DW_SPLIT_MIN_K ? (float *)(ws + t.dwpart) : nullptr;
     // ---- layers, top down ------------------------------------------------------------------------
     const int KT = D * g.kh;
@@ -970,4 +912,201 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
         if (layer_done) layer_done(l, user);   // every kernel that writes layer l's parameter gradients is enqueued
     }
     return TD_OK;
+}
+
+extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                               const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
+                               float *const *grad_layer, float *const *grad_misc, float *grad_film, void *stream_) {
+    return td_rnn_backward_cb(cfg, packT, misc, film, grad_y, batch, seq_len, workspace, grad_layer, grad_misc, grad_film,
+                              nullptr, nullptr, stream_);
+}
+
+extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                                  const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
+                                  float *const *grad_layer, float *const *grad_misc, float *grad_film,
+                                  td_layer_done_fn layer_done, void *user, void *stream_) {
+    TD_REQUIRE(cfg && packT && misc && film && grad_y && workspace && grad_layer && grad_misc && grad_film, "NULL argument");
+    TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int L = seq_len, N = cfg->layers, D = g.dirs, H = cfg->hidden, G = cfg->gru ? 3 : 4;
+    const TdTrainLayout t = td_train_layout(cfg, g, batch, L);
+    const TdPackTGeom tg = td_packT_geom(cfg, g);
+    char *ws = (char *)workspace;
+    const int DH = D * H;
+
+    // ---- head --------------------------------------------------------------------------------
+    TD_HIP(hipMemsetAsync(grad_film, 0, (size_t)batch * 2 * DH * sizeof(float), stream));
+    {
+        TdHeadBwdParams p;
+        p.act = ws + t.act[N - 1];
+        p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.film = film; p.gy = grad_y;
+        p.gout = ws + t.gout[N - 1][0];
+        p.chan = (float *)(ws + t.chan); p.g1 = (float *)(ws + t.g1);
+        p.d_film = grad_film; p.d_ln_w = grad_misc[TD_LN_W]; p.d_ln_b = grad_misc[TD_LN_B];
+        p.d_fc_w = grad_misc[TD_FC_W]; p.d_fc_b = grad_misc[TD_FC_B];
+        TD_REQUIRE(p.d_ln_w && p.d_ln_b && p.d_fc_w && p.d_fc_b, "NULL gradient pointer for the head parameters");
+        p.B = batch; p.L = L; p.nbb = t.nbb; p.H = H; p.hpad = g.hpad; p.kh = g.kh; p.dirs = D; p.c_out = cfg->c_out;
+        const size_t ntask = (size_t)L * t.nbb;
+        int blocks = (int)((ntask + 3) / 4);
+        if (blocks > 2048) blocks = 2048;
+        const int DHP = D * g.hpad;
+        const size_t lds_max = 160 * 1024;
+        auto launch = [&](auto kern, size_t shm) -> int {
+            if (shm) TD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, stream, p);
+            TD_LAUNCH_CHECK();
+            return TD_OK;
+        };
+        const int cm = cfg->c_out <= 16 ? 16 : 32;
+        const size_t shm = (size_t)(1 + cm) * DHP * sizeof(float);
+        if (shm <= lds_max) rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, false>, shm) : launch(td_head_bwd_dh_kernel<32, false>, shm);
+        else rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, true>, 0) : launch(td_head_bwd_dh_kernel<32, true>, 0);
+        if (rc != TD_OK) return rc;
+        const int rows = batch * cfg->c_out;
+        hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, stream, grad_y, p.g1, rows, L);
+        TD_LAUNCH_CHECK();
+        // about 2048 waves per launch, chunks of at least 16 steps
+        p.lch = 2048 / (t.nbb * D * g.kh);
+        if (p.lch > L / 16) p.lch = L / 16;
+        if (p.lch < 1) p.lch = 1;
+        p.llen = td_cdiv(L, p.lch);
+        p.lch = td_cdiv(L, p.llen);
+        hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16) * p.lch), dim3(256), 0,
+                           stream, p);
+        TD_LAUNCH_CHECK();
+    }
+    if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
+    return td_layers_backward(cfg, g, packT, batch, L, ws, grad_layer, layer_done, user, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// TSTR classifier (evaluate/nn_classifier.py:89-127): RNN over (B, C, L) -> the final hidden state of each direction
+// (forward: position L-1, backward: position 0) -> Linear(D*H, 1) -> Sigmoid, trained with binary cross entropy
+// (nn_classifier.py:140-165).  The recurrent layers, their saves and their backward pass are the denoiser's
+// (td_rnn_run_layers_ex / td_layers_backward on the training workspace); only this head is new.
+// ---------------------------------------------------------------------------------------------
+struct TdClsParams {
+    const char *act;         // top layer's output fragments
+    char *gout;              // d h_top fragments (zeroed before the backward kernel runs)
+    const float *w, *b, *y;  // Linear(D*H, 1) weight, bias; labels (or NULL: gprob)
+    const float *gprob;      // d loss / d prob when the loss is not this file's mean BCE
+    float *prob;             // sigmoid(logit), (B)
+    float *d_w, *d_b;        // accumulated
+    int B, L, nbb, H, kh, dirs;
+};
+
+// one wave per batch block; lane (m, hf) holds 8 units per fragment of sequence m
+template <bool BWD>
+__global__ __launch_bounds__(64) void td_cls_head_kernel(TdClsParams p) {
+    const int bblk = blockIdx.x, lane = threadIdx.x, m = lane & 31, hf = lane >> 5;
+    const int b = bblk * 32 + m, KT = p.dirs * p.kh;
+    const bool valid = b < p.B;
+    float dl = 0.f;
+    if (BWD && valid) {
+        const float pr = p.prob[b];
+        dl = p.y ? (pr - p.y[b]) / (float)p.B        // d BCE(mean) / d logit
+                 : p.gprob[b] * pr * (1.0f - pr);    // through the sigmoid
+    }
+    float logit = 0.f;
+    for (int d = 0; d < p.dirs; ++d) {
+        const int l = d ? 0 : p.L - 1;                                   // where direction d's last step sits
+        const size_t frag0 = ((size_t)l * p.nbb + bblk) * KT + d * p.kh;
+        for (int ks = 0; ks < p.kh; ++ks) {
+            const bf16x8 v = *((const bf16x8 *)(p.act + (frag0 + ks) * TD_FRAG_BYTES) + lane);
+            bf16x8 g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int unit = 16 * ks + 8 * (j >> 2) + 4 * hf + (j & 3);
+                const float wv = unit < p.H ? p.w[d * p.H + unit] : 0.f;
+                if (!BWD) logit = fmaf(wv, (float)v[j], logit);
+                else {
+                    g[j] = (__bf16)(dl * wv);
+                    // d w[f] = sum over sequences of d logit * h[f]: over the 32 lanes of the half-wave, then one atomic
+                    float t = dl * (float)v[j];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                    if (m == 0 && unit < p.H) atomicAdd(&p.d_w[d * p.H + unit], t);
+                }
+            }
+            if (BWD) *((bf16x8 *)(p.gout + (frag0 + ks) * TD_FRAG_BYTES) + lane) = g;
+        }
+    }
+    if (!BWD) {
+        logit += __shfl_xor(logit, 32);
+        if (hf == 0 && valid) p.prob[b] = 1.0f / (1.0f + expf(-(logit + p.b[0])));
+    } else {
+        float t = hf == 0 ? dl : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) atomicAdd(p.d_b, t);
+    }
+}
+
+extern "C" size_t td_cls_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len) {
+    return td_rnn_train_workspace_bytes(cfg, batch, seq_len);
+}
+
+// x (B, c_in, L) -> prob (B).  The workspace keeps what td_cls_backward needs.
+extern "C" int td_cls_forward(const td_rnn_config *cfg, const void *packed, const float *x, const float *w, const float *b,
+                              int32_t batch, int32_t seq_len, float *prob, void *workspace, void *stream_) {
+    TD_REQUIRE(cfg && packed && x && w && b && prob && workspace, "NULL argument");
+    TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    TD_REQUIRE(g.dirs * g.kh <= 64, "hidden size beyond the classifier head's range");
+    hipStream_t stream = (hipStream_t)stream_;
+    const TdTrainLayout t = td_train_layout(cfg, g, batch, seq_len);
+    char *ws = (char *)workspace;
+    char *acts[16];
+    float *saves[16];
+    for (int l = 0; l < cfg->layers; ++l) {
+        acts[l] = ws + t.act[l];
+        saves[l] = (float *)(ws + t.save[l]);
+    }
+    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream, nullptr);
+    if (rc != TD_OK) return rc;
+    TdClsParams p;
+    p.act = acts[cfg->layers - 1]; p.gout = nullptr; p.w = w; p.b = b; p.y = nullptr; p.gprob = nullptr; p.prob = prob; p.d_w = nullptr; p.d_b = nullptr;
+    p.B = batch; p.L = seq_len; p.nbb = t.nbb; p.H = cfg->hidden; p.kh = g.kh; p.dirs = g.dirs;
+    hipLaunchKernelGGL((td_cls_head_kernel<false>), dim3(t.nbb), dim3(64), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    // plain copies for the weight-gradient GEMMs of the backward pass
+    hipLaunchKernelGGL(td_x_to_plain_kernel, dim3(2048), dim3(256), 0, stream, x, (__bf16 *)(ws + t.plain[0]), batch, cfg->c_in,
+                       t.cpad, seq_len, t.Bp);
+    TD_LAUNCH_CHECK();
+    for (int l = 0; l < cfg->layers; ++l) {
+        hipLaunchKernelGGL(td_frags_to_plain_kernel, dim3(td_cdiv(t.nbb, 2), seq_len, td_cdiv(g.dirs * g.kh, TD_F2P_FRAGS)), dim3(256), 0,
+                           stream, (const __bf16 *)acts[l], (__bf16 *)(ws + t.plain[l + 1]), seq_len, t.nbb, g.kh, g.dirs);
+        TD_LAUNCH_CHECK();
+    }
+    return TD_OK;
+}
+
+// Backward through the head and the recurrent layers of the last td_cls_forward on this workspace, of mean binary cross
+// entropy(prob, y) when y is given, otherwise of a loss whose gradient w.r.t. prob is grad_prob: ACCUMULATES into grad_layer (4 tensors per layer and direction, torch layout), grad_w (D*H), grad_b (1).
+extern "C" int td_cls_backward(const td_rnn_config *cfg, const void *packT, const float *w, const float *prob, const float *y,
+                               const float *grad_prob, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer,
+                               float *grad_w, float *grad_b, void *stream_) {
+    TD_REQUIRE(cfg && packT && w && prob && (y || grad_prob) && workspace && grad_layer && grad_w && grad_b, "NULL argument");
+    TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const TdTrainLayout t = td_train_layout(cfg, g, batch, seq_len);
+    char *ws = (char *)workspace;
+    const int top = cfg->layers - 1;
+    TD_HIP(hipMemsetAsync(ws + t.gout[top][0], 0, t.act_bytes, stream));
+    TdClsParams p;
+    p.act = ws + t.act[top]; p.gout = ws + t.gout[top][0]; p.w = w; p.b = nullptr; p.y = y; p.gprob = grad_prob; p.prob = (float *)prob;
+    p.d_w = grad_w; p.d_b = grad_b;
+    p.B = batch; p.L = seq_len; p.nbb = t.nbb; p.H = cfg->hidden; p.kh = g.kh; p.dirs = g.dirs;
+    hipLaunchKernelGGL((td_cls_head_kernel<true>), dim3(t.nbb), dim3(64), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    return td_layers_backward(cfg, g, packT, batch, seq_len, ws, grad_layer, nullptr, nullptr, stream);
 }

@@ -17,8 +17,7 @@ _GAUSS_BUFFERS = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas
 class GaussianDiffusion(nn.Module):
     def __init__(self, model, seq_length, channels, timesteps=1000, beta_schedule="cosine", auto_normalize=True):
         super().__init__()
-        if not auto_normalize:
-            raise NotImplementedError("auto_normalize=False is not reachable from the reference's CLI defaults")
+        self.auto_normalize = bool(auto_normalize)     # False: the data is diffused as given (gaussian_diffusion.py:95-96)
         self.model = model
         self.channels = channels
         self.self_condition = self.model.self_condition
@@ -37,7 +36,7 @@ class GaussianDiffusion(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("GaussianDiffusion runs on the MI355X only: move the module to a ROCm device")
             self._kernels = DiffusionKernels(list(range(self.channels)), [], [], self.seq_length, self.num_timesteps,
-                                             self._all_tables, self.channels, dev)
+                                             self._all_tables, self.channels, dev, auto_normalize=self.auto_normalize)
             self._sampler = None
         return self._kernels
 

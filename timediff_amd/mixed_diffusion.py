@@ -43,8 +43,7 @@ class MixedDiffusion(nn.Module):
         super().__init__()
         if parametrization != "x0":
             raise ValueError("Unknown parametrization: {}".format(parametrization))
-        if not auto_normalize:
-            raise NotImplementedError("auto_normalize=False is not reachable from the reference's CLI defaults")
+        self.auto_normalize = bool(auto_normalize)     # False: the continuous channels are diffused as given (:160-162)
         self.model = model
         self.channels = channels
         self.self_condition = self.model.self_condition
@@ -92,7 +91,7 @@ class MixedDiffusion(nn.Module):
                 self.numerical_features_indices, self.categorical_features_indices,
                 [int(k) for k in self.categorical_num_classes], self.seq_length, self.num_timesteps, self._tables(),
                 # create_samples (:173-179) sizes the result `channels - n_cat`
-                self.channels - n_cat, dev)
+                self.channels - n_cat, dev, auto_normalize=self.auto_normalize)
             self._sampler = None
         return self._kernels
 
@@ -115,7 +114,8 @@ class MixedDiffusion(nn.Module):
             t = torch.randint(0, self.num_timesteps, (b,), device=dev).long()
         x_in, x0_idx, xt_idx, eps = dk.q_sample(sample, t, noise, uniforms, seed=_fresh_seed(), tag=0x40000000)
         # the reference normalises the caller's batch in place (normalize_numericals, :189-194)
-        sample[:, self.numerical_features_indices, :] = sample[:, self.numerical_features_indices, :] * 2 - 1
+        if self.auto_normalize:
+            sample[:, self.numerical_features_indices, :] = sample[:, self.numerical_features_indices, :] * 2 - 1
         model_out = self.model(x_in, t, None)
         return _LossFn.apply(model_out, dk, eps, x0_idx, xt_idx, t, float(self.loss_lambda))
 

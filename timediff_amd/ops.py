@@ -177,7 +177,7 @@ class DiffusionKernels:
     """The MixedDiffusion arithmetic (mixed_diffusion.py) on the HIP kernels; `num_classes=[]` gives the
     Gaussian process of gaussian_diffusion.py."""
 
-    def __init__(self, num_index, cat_index, num_classes, seq_len, timesteps, tables, data_channels, device):
+    def __init__(self, num_index, cat_index, num_classes, seq_len, timesteps, tables, data_channels, device, auto_normalize=True):
         self.n_num, self.n_cat = len(num_index), len(cat_index)
         self.K = [int(k) for k in num_classes]
         self.sumk = sum(self.K)
@@ -186,7 +186,7 @@ class DiffusionKernels:
         self.data_channels = data_channels
         self.tables = torch.stack([tables[k].to(device=device, dtype=torch.float32) for k in _lib.TAB_ROWS]).contiguous()
         cfg = DiffusionConfig(n_num=self.n_num, n_cat=self.n_cat, seq_len=seq_len, timesteps=timesteps,
-                              data_channels=data_channels, tables=self.tables.data_ptr())
+                              data_channels=data_channels, raw_range=0 if auto_normalize else 1, tables=self.tables.data_ptr())
         for i, k in enumerate(self.K):
             cfg.num_classes[i] = k
         for i, v in enumerate(num_index):
