@@ -187,6 +187,28 @@ def test_dataset_cache_roundtrip(tmp_path):
                                atol=1e-4)
 
 
+def test_dataset_streamed_build_equals_in_memory(tmp_path, monkeypatch):
+    """The cache built in chunks of samples (two streamed passes, memory-mapped staging) equals fill-then-normalise on
+    the whole tensor (utils.py:24-27: replace_nan_with_mean, then normalize_data), and batches come back in request order."""
+    from timediff_amd import data as D
+    torch.manual_seed(3)
+    raw = torch.randn(53, 5, 11) * 4 + 1
+    raw[:, 3, :] = (torch.rand(53, 11) > 0.3).float()
+    raw[torch.rand(53, 5, 11) < 0.1] = float("nan")
+    raw[:, 3, :] = torch.nan_to_num(raw[:, 3, :], nan=1.0)
+    torch.save(raw, tmp_path / "raw.pt")
+    monkeypatch.setattr(D.TimeSeriesDataset, "CHUNK", 7)
+    ds = D.TimeSeriesDataset("toy", [3], 9, load_path=str(tmp_path / "raw.pt"), root=str(tmp_path / "datasets"))
+    want, lo, hi = D.normalize_data(D.replace_nan_with_mean(raw), [3])
+    assert torch.allclose(ds.data, want[:, :, :9], rtol=0, atol=2e-6)
+    assert torch.allclose(ds.min, lo, atol=1e-6) and torch.allclose(ds.max, hi, atol=1e-6)
+    assert not os.path.exists(tmp_path / "datasets" / "toy" / "data.pt.stage")
+    idx = [40, 3, 17, 3, 52, 0]
+    assert torch.equal(ds.__getitems__(idx), ds.data[torch.tensor(idx)])
+    with pytest.raises(AssertionError):
+        D.TimeSeriesDataset("other", [3], 9, load_path=str(tmp_path / "missing.pt"), root=str(tmp_path / "datasets"))
+
+
 def test_layer_slices_and_uncovered_ranges():
     """The flat gradient buffer's per-layer all-reduce slices (ETDiff._layer_reduce) and what is left for the end."""
     import torch.nn as nn
