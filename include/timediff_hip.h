@@ -119,6 +119,14 @@ TD_API int td_rnn_read_hidden(const td_rnn_config *cfg, const void *workspace, i
  * like `packed`.  Gradients are computed from bf16-rounded activations and gate gradients with fp32
  * accumulation; float atomics make the last bits run-dependent. */
 TD_API size_t td_rnn_train_workspace_bytes(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
+/* Inter-layer dropout of nn.LSTM / nn.GRU (`dropout=` of blocks.py:268-270; etdiff_train.py --dropout): in training
+ * every layer's output but the top one's is multiplied by a Bernoulli(1 - p) mask / (1 - p) on its way to the next layer.
+ * Process-wide, like the kernel-selection knobs: td_rnn_train_workspace_bytes, td_rnn_forward_train and
+ * td_rnn_backward[_cb] read it (a backward pass must see the (p, seed) of its forward pass: the mask is regenerated
+ * from a counter-based generator, not stored); inference entry points never drop.  p is quantised to 1/65536.
+ * td_rnn_dropout_mask writes layer `layer`'s mask as (B, L, D*H) fp32 (entries 0 or 1/(1-p)) for parity checks. */
+TD_API int td_rnn_set_dropout(float p, uint64_t seed);
+TD_API int td_rnn_dropout_mask(const td_rnn_config *cfg, int32_t batch, int32_t seq_len, int32_t layer, float *mask, void *stream);
 TD_API size_t td_rnn_packT_bytes(const td_rnn_config *cfg);
 TD_API int td_rnn_pack_weights_T(const td_rnn_config *cfg, const float *const *layer_weights_host, void *packT, void *stream);
 TD_API int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed, const float *const *misc_host, const float *x,

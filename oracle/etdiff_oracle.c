@@ -260,16 +260,27 @@ static void rnn_dir(const OrRnnCfg *c, const float *w_ih, const float *w_hh, con
     free(whh_r);
 }
 
+/* Inter-layer dropout (nn.LSTM / nn.GRU `dropout=`, blocks.py:268-270) with the masks GIVEN: (N-1, B, L, D*H) fp32,
+ * entries 0 or 1/(1-p), multiplied onto every layer's output but the top one's on its way to the next layer.  NULL: none.
+ * (torch draws its masks from its own generator; a parity run hands both sides the same ones.) */
+static const float *g_drop = NULL;
+static int g_drop_B = 0;
+EXPORT void or_set_dropout_masks(const float *masks, int B) { g_drop = masks; g_drop_B = B; }
+static const float *drop_mask(const OrRnnCfg *c, int layer, int b, int L) {
+    return g_drop + ((size_t)layer * g_drop_B + b) * L * c->D * c->H;
+}
+
 /* Per-sequence forward.  bufs: layer outputs (N+1 of them; [0] is the transposed input). */
 typedef struct {
     float **layer_out; /* [N+1] each (L, width) */
+    float **layer_in;  /* [N] layer l's input: layer_out[l], or its dropped copy */
     float **act;       /* [N*D] each (L, 5H|4H) or NULL */
     float *xhat, *rstd; /* (L, DH), (L) */
     float *temb, *h1pre, *h1, *sinus, *film;
 } SeqSave;
 
 static void rnn_forward_seq(const OrRnnCfg *c, const float *const *lw, const float *const *misc, const float *x /*(C,L)*/,
-                            int L, int64_t t, float *y /*(C_out,L)*/, float *hidden /*(L,DH) or NULL*/, SeqSave *sv) {
+                            int b, int L, int64_t t, float *y /*(C_out,L)*/, float *hidden /*(L,DH) or NULL*/, SeqSave *sv) {
     const int H = c->H, D = c->D, DH = D * H;
     float *bufA = (float *)malloc(sizeof(float) * (size_t)L * (c->C_in > DH ? c->C_in : DH));
     float *bufB = (float *)malloc(sizeof(float) * (size_t)L * DH);
@@ -294,6 +305,12 @@ static void rnn_forward_seq(const OrRnnCfg *c, const float *const *lw, const flo
         }
         in = out;
         In = DH;
+        if (g_drop && layer + 1 < c->N) {
+            const float *m = drop_mask(c, layer, b, L);
+            float *dst = sv ? sv->layer_in[layer + 1] : out;
+            for (size_t i = 0; i < (size_t)L * DH; ++i) dst[i] = out[i] * m[i];
+            in = dst;
+        }
     }
     if (hidden) memcpy(hidden, out, sizeof(float) * (size_t)L * DH);
     const float *ln_w = misc[M_LN_W], *ln_b = misc[M_LN_B], *fc_w = misc[M_FC_W], *fc_b = misc[M_FC_B];
@@ -323,7 +340,7 @@ EXPORT void or_rnn_forward(const OrRnnCfg *c, const float *const *lw, const floa
                            const int64_t *t, int B, int L, float *y, float *hidden) {
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b)
-        rnn_forward_seq(c, lw, misc, x + (size_t)b * c->C_in * L, L, t[b], y + (size_t)b * c->C_out * L,
+        rnn_forward_seq(c, lw, misc, x + (size_t)b * c->C_in * L, b, L, t[b], y + (size_t)b * c->C_out * L,
                         hidden ? hidden + (size_t)b * L * c->D * c->H : NULL, NULL);
 }
 
@@ -340,6 +357,9 @@ EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const flo
         sv.act = (float **)malloc(sizeof(float *) * c->N * D);
         sv.layer_out[0] = (float *)malloc(sizeof(float) * (size_t)L * c->C_in);
         for (int l = 1; l <= c->N; ++l) sv.layer_out[l] = (float *)malloc(sizeof(float) * (size_t)L * DH);
+        sv.layer_in = (float **)malloc(sizeof(float *) * c->N);
+        for (int l = 0; l < c->N; ++l)
+            sv.layer_in[l] = (g_drop && l > 0) ? (float *)malloc(sizeof(float) * (size_t)L * DH) : sv.layer_out[l];
         for (int i = 0; i < c->N * D; ++i) sv.act[i] = (float *)malloc(sizeof(float) * (size_t)L * AW);
         sv.xhat = (float *)malloc(sizeof(float) * (size_t)L * DH);
         sv.rstd = (float *)malloc(sizeof(float) * L);
@@ -349,7 +369,7 @@ EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const flo
         sv.sinus = (float *)malloc(sizeof(float) * c->embed_dim);
         sv.film = (float *)malloc(sizeof(float) * 2 * DH);
         float *y = (float *)malloc(sizeof(float) * (size_t)c->C_out * L);
-        rnn_forward_seq(c, lw, misc, x + (size_t)b * c->C_in * L, L, t[b], y, NULL, &sv);
+        rnn_forward_seq(c, lw, misc, x + (size_t)b * c->C_in * L, b, L, t[b], y, NULL, &sv);
         if (y_out) memcpy(y_out + (size_t)b * c->C_out * L, y, sizeof(float) * (size_t)c->C_out * L);
         const float *g = gy + (size_t)b * c->C_out * L;
         const float *ln_w = misc[M_LN_W], *ln_b = misc[M_LN_B], *fc_w = misc[M_FC_W];
@@ -425,7 +445,7 @@ EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const flo
         float *dout = dh_top; /* (L, DH) gradient w.r.t. this layer's output */
         for (int layer = c->N - 1; layer >= 0; --layer) {
             int In = layer == 0 ? c->C_in : DH;
-            const float *in = sv.layer_out[layer];
+            const float *in = sv.layer_in[layer];
             const float *outp = sv.layer_out[layer + 1];
             float *din = (float *)calloc((size_t)L * In, sizeof(float));
             for (int d = 0; d < D; ++d) {
@@ -488,6 +508,10 @@ EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const flo
                     memcpy(dh, dhp, sizeof dhp);
                 }
             }
+            if (g_drop && layer > 0) {   /* d(dropped output) -> d(output of the layer below) */
+                const float *m = drop_mask(c, layer - 1, b, L);
+                for (size_t i = 0; i < (size_t)L * DH; ++i) din[i] *= m[i];
+            }
             free(dout);
             dout = din;
         }
@@ -495,9 +519,11 @@ EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const flo
             for (int l = 0; l < L; ++l)
                 for (int ch = 0; ch < c->C_in; ++ch) gx[((size_t)b * c->C_in + ch) * L + l] = dout[(size_t)l * c->C_in + ch];
         free(dout);
+        for (int l = 1; l < c->N; ++l)
+            if (sv.layer_in[l] != sv.layer_out[l]) free(sv.layer_in[l]);
         for (int l = 0; l <= c->N; ++l) free(sv.layer_out[l]);
         for (int i = 0; i < c->N * D; ++i) free(sv.act[i]);
-        free(sv.layer_out); free(sv.act); free(sv.xhat); free(sv.rstd); free(sv.temb); free(sv.h1pre); free(sv.h1);
+        free(sv.layer_in); free(sv.layer_out); free(sv.act); free(sv.xhat); free(sv.rstd); free(sv.temb); free(sv.h1pre); free(sv.h1);
         free(sv.sinus); free(sv.film); free(y);
     }
 }

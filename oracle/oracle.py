@@ -131,17 +131,29 @@ class Denoiser:
         lib().or_time_embed(C.byref(self.cfg), self._misc, _ptr(t, C.c_int64), B, _ptr(temb), _ptr(film))
         return temb, film
 
-    def forward(self, x, t, want_hidden=False):
+    def _set_masks(self, masks, B, L):
+        """masks: (N-1, B, L, D*H) multiplicative inter-layer dropout masks (entries 0 or 1/(1-p)), or None."""
+        if masks is None:
+            lib().or_set_dropout_masks(None, 0)
+            return None
+        masks = _f32(masks)
+        assert masks.shape == (self.cfg.N - 1, B, L, self.cfg.D * self.cfg.H), masks.shape
+        lib().or_set_dropout_masks(_ptr(masks), B)
+        return masks
+
+    def forward(self, x, t, want_hidden=False, masks=None):
         x = _f32(x)
         t = np.ascontiguousarray(t, dtype=np.int64)
         B, _, L = x.shape
         y = np.empty((B, self.cfg.C_out, L), np.float32)
         hidden = np.empty((B, L, self.cfg.D * self.cfg.H), np.float32) if want_hidden else None
+        masks = self._set_masks(masks, B, L)
         lib().or_rnn_forward(C.byref(self.cfg), self._lw, self._misc, _ptr(x), _ptr(t, C.c_int64), B, L, _ptr(y),
                              _ptr(hidden))
+        self._set_masks(None, B, L)
         return (y, hidden) if want_hidden else y
 
-    def backward(self, x, t, grad_y):
+    def backward(self, x, t, grad_y, masks=None):
         """-> (y, grad_x, {param name: grad})"""
         x = _f32(x)
         gy = _f32(grad_y)
@@ -153,8 +165,10 @@ class Denoiser:
         _gmisc = (C.POINTER(C.c_float) * len(gmisc))(*[_ptr(a) for a in gmisc])
         gx = np.empty_like(x)
         y = np.empty((B, self.cfg.C_out, L), np.float32)
+        masks = self._set_masks(masks, B, L)
         lib().or_rnn_backward(C.byref(self.cfg), self._lw, self._misc, _ptr(x), _ptr(t, C.c_int64), B, L, _ptr(gy),
                               _glw, _gmisc, _ptr(gx), _ptr(y))
+        self._set_masks(None, B, L)
         grads = dict(zip(self.lkeys, glw))
         grads.update(dict(zip(MISC_KEYS, gmisc)))
         return y, gx, grads

@@ -63,6 +63,8 @@ _SIGS = {
     "td_rnn_forward": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "td_rnn_read_hidden": (C.c_int, [C.POINTER(RnnConfig), _P, _I, _I, _P, _P]),
     "td_rnn_train_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
+    "td_rnn_set_dropout": (C.c_int, [C.c_float, C.c_uint64]),
+    "td_rnn_dropout_mask": (C.c_int, [C.POINTER(RnnConfig), _I, _I, _I, _P, _P]),
     "td_rnn_packT_bytes": (C.c_size_t, [C.POINTER(RnnConfig)]),
     "td_rnn_pack_weights_T": (C.c_int, [C.POINTER(RnnConfig), C.POINTER(_P), _P, _P]),
     "td_rnn_forward_train": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, _P, _P]),

@@ -11,6 +11,11 @@ class _DenoiserFn(torch.autograd.Function):
     def forward(ctx, module, x, time, *params):
         k = module.kernels()
         film = k.time_film(time)
+        # inter-layer dropout (training mode only, as nn.LSTM): a fresh 64-bit seed per call from torch's generator, so
+        # torch.manual_seed makes a run repeatable; the backward pass re-sets the same (p, seed)
+        p = module.dropout if module.training else 0.0
+        ctx.dropout = (p, int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+        k.set_dropout(*ctx.dropout)
         y = k.forward_train(x, film)
         ctx.module = module
         ctx.save_for_backward(film, time)
@@ -20,6 +25,7 @@ class _DenoiserFn(torch.autograd.Function):
     def backward(ctx, grad_y):
         film, time = ctx.saved_tensors
         k = ctx.module.kernels()
+        k.set_dropout(*ctx.dropout)
         sink = getattr(ctx.module, "_grad_sink", None)
         if sink is not None:
             # the trainer's flat gradient buffer: the kernels accumulate straight into the .grad views (no

@@ -49,8 +49,9 @@ class RNN(nn.Module):
     def __init__(self, input_channels, hidden_channels, output_channels, layers, model="lstm", dropout=0,
                  bidirectional=True, self_condition=False, embed_dim=64, time_dim=256):
         super().__init__()
-        if dropout != 0:
-            raise NotImplementedError("inter-layer dropout is not implemented (the reference's CLI default is 0)")
+        if not 0 <= dropout < 1:
+            raise ValueError(f"dropout should be a number in range [0, 1), got {dropout}")
+        self.dropout = float(dropout) if layers > 1 else 0.0      # nn.LSTM: no effect (a warning) with one layer
         if self_condition:
             raise NotImplementedError("self_condition is never enabled by the reference's CLI (etdiff_train.py:224, :245)")
         self.self_condition = self_condition

@@ -782,21 +782,24 @@ struct TdHeadFuseRun {
     float *hpart;
     int hp_stride;
 };
+// [l_first, l_end): the layers to run (default: all); the layer-0 fragments are packed when l_first == 0
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
-                         char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse = nullptr) {
+                         char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse = nullptr,
+                         int l_first = 0, int l_end = -1) {
     TdRnnGeom g;
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
     const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
-    if (x) {   // x == nullptr: x0 already holds the layer-0 fragments (td_rnn_run_layers_state)
+    if (l_end < 0) l_end = cfg->layers;
+    if (x && l_first == 0) {   // x == nullptr: x0 already holds the layer-0 fragments (the sampler's state path)
         size_t total = (size_t)L * nbb * g.kx0 * 64;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(td_pack_input_kernel, dim3(blocks), dim3(256), 0, stream, x, x0, batch, cfg->c_in, L, nbb, g.kx0);
         TD_LAUNCH_CHECK();
     }
-    const char *in = x0;
-    for (int l = 0; l < cfg->layers; ++l) {
+    const char *in = l_first == 0 ? x0 : acts[l_first - 1];
+    for (int l = l_first; l < l_end; ++l) {
         const TdLayerGeom &lg = l == 0 ? g.g0 : g.g1;
         TdLayerParams p;
         p.wpacked = (const char *)packed + g.layer_off[l];

@@ -13,6 +13,7 @@
 //     bias_reduce d b = row sums of d a   (H > 256 only: the sweeps up to 256 accumulate them in registers)
 #include "rnn_cluster.h"
 #include "rnn_launch.h"
+#include "rng.h"
 
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
     return td_launch_layer_dispatch(gru, 1, nu, p, layer0, kxsel, stream);
@@ -22,7 +23,8 @@ size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);   // rnn_cluster.h
 int td_layer_kernel_mode(void);   // api.cpp
 struct TdHeadFuseRun;   // rnn.hip: the sampler's fused head, not used in training
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
-                         char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse);
+                         char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse,
+                         int l_first, int l_end);
 // gemm_lib.cpp (rocBLAS)
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
                    int nsplit, float *partial, hipStream_t stream);
@@ -45,11 +47,80 @@ static int td_dw_nsplit(int M, int N, int K) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// inter-layer dropout (nn.LSTM / nn.GRU `dropout=`, blocks.py:268-270: every layer's output but the last one's is
+// multiplied by a Bernoulli(1 - p) mask / (1 - p) on its way to the next layer, in training mode)
+// ---------------------------------------------------------------------------------------------
+static float g_dropout_p = 0.f;
+static uint64_t g_dropout_seed = 0;
+float td_dropout_p(void) { return g_dropout_p; }
+
+// Process-wide (like the kernel-selection knobs): read by td_rnn_forward_train, td_rnn_backward[_cb] and
+// td_rnn_train_workspace_bytes; a backward pass must see the values its forward pass saw.
+extern "C" int td_rnn_set_dropout(float p, uint64_t seed) {
+    TD_REQUIRE(p >= 0.f && p < 1.f, "dropout probability must be in [0, 1), got %g", (double)p);
+    g_dropout_p = p;
+    g_dropout_seed = seed;
+    return TD_OK;
+}
+
+// One thread per 16-byte fragment row (8 elements): ONE Philox block gives eight 16-bit uniforms; element j is kept where
+// its field >= thresh = round(p * 65536).  The counter is (row index, layer), so the backward pass regenerates the mask of
+// the forward pass on the gradient fragments (same layout) instead of reading a stored one.
+__device__ __forceinline__ unsigned td_dropout_field(const Philox4 &r, int j) { return (r.v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
+
+__global__ __launch_bounds__(256) void td_dropout_frags_kernel(bf16x8 *__restrict__ frags, size_t nvec, int layer, unsigned thresh,
+                                                               float scale, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const Philox4 r = td_philox((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)layer, 0xD0D0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        bf16x8 v = frags[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = td_dropout_field(r, j) >= thresh ? (__bf16)((float)v[j] * scale) : (__bf16)0.f;
+        frags[i] = v;
+    }
+}
+
+// the mask itself, (B, L, D*H) fp32 with entries 0 or 1 / (1 - p): parity runs feed it to the oracle
+__global__ __launch_bounds__(256) void td_dropout_mask_kernel(float *__restrict__ mask, int B, int L, int nbb, int H, int kh, int dirs,
+                                                              int layer, unsigned thresh, float scale, uint64_t seed) {
+    const size_t total = (size_t)B * L * dirs * H;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int feat = (int)(idx % (dirs * H)), l = (int)((idx / (dirs * H)) % L), b = (int)(idx / ((size_t)dirs * H * L));
+        const int d = feat / H, unit = feat % H, ks = unit / 16, w = unit % 16, hf = (w >> 2) & 1, j = ((w >> 3) << 2) | (w & 3);
+        const size_t i = (((size_t)l * nbb + b / 32) * (dirs * kh) + d * kh + ks) * 64 + hf * 32 + (b % 32);
+        const Philox4 r = td_philox((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)layer, 0xD0D0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        mask[idx] = td_dropout_field(r, j) >= thresh ? scale : 0.f;
+    }
+}
+
+static inline unsigned td_dropout_thresh(void) { return (unsigned)(g_dropout_p * 65536.0f + 0.5f); }
+static inline float td_dropout_scale(void) { return 1.0f / (1.0f - (float)td_dropout_thresh() / 65536.0f); }
+
+static int td_dropout_apply(char *frags, size_t bytes, int layer, hipStream_t stream) {
+    const size_t nvec = bytes / 16;
+    hipLaunchKernelGGL(td_dropout_frags_kernel, dim3((unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192)), dim3(256), 0, stream,
+                       (bf16x8 *)frags, nvec, layer, td_dropout_thresh(), td_dropout_scale(), g_dropout_seed);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+extern "C" int td_rnn_dropout_mask(const td_rnn_config *cfg, int32_t batch, int32_t seq_len, int32_t layer, float *mask, void *stream) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    TD_REQUIRE(mask && batch > 0 && seq_len > 0 && layer >= 0 && layer < cfg->layers - 1, "bad argument");
+    hipLaunchKernelGGL(td_dropout_mask_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, mask, batch, seq_len,
+                       td_cdiv(batch, TD_WAVE_BATCH), cfg->hidden, g.kh, g.dirs, layer, td_dropout_thresh(), td_dropout_scale(),
+                       g_dropout_seed);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // training workspace
 // ---------------------------------------------------------------------------------------------
 struct TdTrainLayout {
     int nbb, Bp, cpad;      // batch blocks, padded batch, layer-0 channels padded to 32
-    size_t x0, act[16], save[16], plain[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, dwpart, total;
+    size_t x0, act[16], save[16], plain[17], plainx[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, dwpart, total;
     size_t act_bytes, save_dir_floats, daf_bytes, dapl_slab_elems, cols;
 };
 
@@ -70,6 +141,10 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
     for (int l = 0; l < cfg->layers; ++l) t.save[l] = take(t.save_dir_floats * g.dirs * sizeof(float));
     t.plain[0] = take((size_t)t.cpad * t.cols * 2);
     for (int l = 1; l <= cfg->layers; ++l) t.plain[l] = take((size_t)g.dirs * g.hpad * t.cols * 2);
+    // inter-layer dropout: layer l's input is the dropped copy of layer l-1's output (the weight gradients of W_ih read it),
+    // while W_hh's read the output itself; without dropout the two are one buffer
+    for (int l = 0; l <= cfg->layers; ++l)
+        t.plainx[l] = (td_dropout_p() > 0.f && l >= 1 && l < cfg->layers) ? take((size_t)g.dirs * g.hpad * t.cols * 2) : t.plain[l];
     for (int l = 0; l < cfg->layers; ++l)
         for (int s = 0; s < 2; ++s) t.gout[l][s] = take(t.act_bytes);
     for (int l = 0; l < cfg->layers; ++l)
@@ -161,20 +236,29 @@ extern "C" int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed
         saves[l] = (float *)(ws + t.save[l]);
     }
     // wide layers: the recurrent-state scratch is the d c carry region of the backward pass ([bblk][u][1024] fp32 per
-    // direction, contiguous: td_train_layout)
-    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream, nullptr);
-    if (rc != TD_OK) return rc;
+    // direction, contiguous: td_train_layout).  Layer by layer: the plain (row-major) bf16 copies the weight-gradient GEMMs
+    // read are taken right behind each layer, and with dropout the layer's output is then masked in place for the next one.
+    const bool drop = td_dropout_p() > 0.f;
+    for (int l = 0; l < cfg->layers; ++l) {
+        rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream, nullptr, l, l + 1);
+        if (rc != TD_OK) return rc;
+        const dim3 grid(td_cdiv(t.nbb, 2), seq_len, td_cdiv(g.dirs * g.kh, TD_F2P_FRAGS));
+        hipLaunchKernelGGL(td_frags_to_plain_kernel, grid, dim3(256), 0, stream, (const __bf16 *)acts[l], (__bf16 *)(ws + t.plain[l + 1]),
+                           seq_len, t.nbb, g.kh, g.dirs);
+        TD_LAUNCH_CHECK();
+        if (drop && l + 1 < cfg->layers) {
+            rc = td_dropout_apply(acts[l], t.act_bytes, l, stream);
+            if (rc != TD_OK) return rc;
+            hipLaunchKernelGGL(td_frags_to_plain_kernel, grid, dim3(256), 0, stream, (const __bf16 *)acts[l],
+                               (__bf16 *)(ws + t.plainx[l + 1]), seq_len, t.nbb, g.kh, g.dirs);
+            TD_LAUNCH_CHECK();
+        }
+    }
     rc = td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, batch, nullptr, batch, seq_len, y, stream);
     if (rc != TD_OK) return rc;
-    // plain copies for the weight-gradient GEMMs
     hipLaunchKernelGGL(td_x_to_plain_kernel, dim3(2048), dim3(256), 0, stream, x, (__bf16 *)(ws + t.plain[0]), batch, cfg->c_in,
                        t.cpad, seq_len, t.Bp);
     TD_LAUNCH_CHECK();
-    for (int l = 0; l < cfg->layers; ++l) {
-        hipLaunchKernelGGL(td_frags_to_plain_kernel, dim3(td_cdiv(t.nbb, 2), seq_len, td_cdiv(g.dirs * g.kh, TD_F2P_FRAGS)), dim3(256), 0,
-                           stream, (const __bf16 *)acts[l], (__bf16 *)(ws + t.plain[l + 1]), seq_len, t.nbb, g.kh, g.dirs);
-        TD_LAUNCH_CHECK();
-    }
     return TD_OK;
 }
 
@@ -862,6 +946,11 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = 2; q.slab[3] = 3;
                 hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(D * g.nu, 4), L * t.nbb), dim3(256), 0, stream, q);
                 TD_LAUNCH_CHECK();
+                // d x is the gradient w.r.t. the DROPPED output of the layer below: the same mask takes it to that output
+                if (td_dropout_p() > 0.f) {
+                    rc = td_dropout_apply(ws + t.gout[l - 1][d], t.act_bytes, l - 1, stream);
+                    if (rc != TD_OK) return rc;
+                }
             }
         }
         // weight and bias gradients
@@ -879,7 +968,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 q.kchunk = 2048;
                 // W_ih
                 q.A = dapl + (size_t)slab_x * t.dapl_slab_elems; q.lda = t.cols;
-                q.B = (const __bf16 *)(ws + t.plain[l]); q.ldb = t.cols;
+                q.B = (const __bf16 *)(ws + t.plainx[l]); q.ldb = t.cols;     // this layer's input (the dropped copy, with dropout)
                 q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = GM * H; q.K = (int)t.cols;
                 if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
                 else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
@@ -1068,7 +1157,7 @@ extern "C" int td_cls_forward(const td_rnn_config *cfg, const void *packed, cons
         acts[l] = ws + t.act[l];
         saves[l] = (float *)(ws + t.save[l]);
     }
-    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream, nullptr);
+    rc = td_rnn_run_layers_ex(cfg, packed, x, batch, seq_len, ws + t.x0, acts, saves, (float *)(ws + t.dc[0]), stream, nullptr, 0, -1);
     if (rc != TD_OK) return rc;
     TdClsParams p;
     p.act = acts[cfg->layers - 1]; p.gout = nullptr; p.w = w; p.b = b; p.y = nullptr; p.gprob = nullptr; p.prob = prob; p.d_w = nullptr; p.d_b = nullptr;

@@ -119,6 +119,17 @@ class DenoiserKernels:
 
 
     # -- training -------------------------------------------------------------------------------
+    @staticmethod
+    def set_dropout(p, seed=0):
+        """Inter-layer dropout of the NEXT forward_train / backward pair (process-wide, td_rnn_set_dropout)."""
+        check(lib().td_rnn_set_dropout(float(p), int(seed)))
+
+    def dropout_mask(self, batch, seq_len, layer):
+        """(B, L, D*H) mask the current (p, seed) puts on layer `layer`'s output (parity checks)."""
+        m = torch.empty(batch, seq_len, self.cfg.dirs * self.cfg.hidden, dtype=torch.float32, device=self.device)
+        check(lib().td_rnn_dropout_mask(C.byref(self.cfg), batch, seq_len, layer, ptr(m), _stream()))
+        return m
+
     def forward_train(self, x, film):
         """Forward that keeps the activations for `backward` (one film row per batch element)."""
         x, film = _f32(x), _f32(film)
