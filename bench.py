@@ -96,6 +96,55 @@ def cpu_baseline(sd, cols, L, T, tables, seconds_target=15.0):
                        f"{per_step:.2f} s/step, extrapolated to T={T}")
 
 
+def parity_gates(dev, den, diff, sd, cols, L, T, tables, B=32):
+    """SURVEY.md 8(d) "parity gates reported next to perf", at the bench's own architecture and weights on a small
+    batch: the HIP path against the CPU oracle (the checker, as in tests/) at t in {T-1, T/2, 10, 0} -- denoiser output,
+    the reverse update's x0_hat / posterior mean / log theta, sampled class ids wherever the Gumbel-perturbed top-2
+    margin exceeds the tolerance, and the loss with its gradient."""
+    from oracle import oracle as orc
+    o16, o32 = orc.Denoiser({k: v.numpy() for k, v in sd.items()}, bf16=True), orc.Denoiser({k: v.numpy() for k, v in sd.items()})
+    od = orc.Diffusion(len(cols["num"]), cols["K"], L, T, tables=tables)
+    rng = np.random.default_rng(11)
+    n_num, n_cat, sumk = len(cols["num"]), len(cols["K"]), sum(cols["K"])
+    gates = {}
+    for t in (T - 1, T // 2, min(10, T - 1), 0):
+        z = rng.standard_normal((B, n_num, L)).astype(np.float32)
+        idx = rng.integers(0, 2, (B, n_cat, L)).astype(np.uint8)
+        noise = rng.standard_normal(z.shape).astype(np.float32)
+        uni = rng.random((B, sumk, L), dtype=np.float32)
+        tt = np.full((B,), t, np.int64)
+        x_in = od.build_x_in(z, idx)
+        mo = den.forward(torch.from_numpy(x_in).to(dev), torch.from_numpy(tt).to(dev))
+        mo_h = mo.cpu().numpy()
+        zg, ig = torch.from_numpy(z).to(dev), torch.from_numpy(idx).to(dev)
+        x0, mean, lth = (a.cpu().numpy() for a in diff.reverse_step_terms(mo, zg, ig, t))
+        z_ref, idx_ref, det = od.reverse_step(mo_h, z, idx, tt, noise, uni, details=True)
+        diff.reverse_step_(mo, zg, ig, t, noise=torch.from_numpy(noise).to(dev), uniforms=torch.from_numpy(uni).to(dev))
+        margin = od.gumbel_margin(det["log_theta"], uni)
+        tol = 1e-3 if t <= 10 else 1e-5
+        clear = margin > tol
+        gates[f"t={t}"] = dict(
+            model_out_vs_bf16_oracle=float(np.abs(mo_h - o16.forward(x_in, tt)).max()),
+            model_out_vs_fp32_oracle=float(np.abs(mo_h - o32.forward(x_in, tt)).max()),
+            x0_hat=float(np.abs(x0 - det["x0"]).max()), posterior_mean=float(np.abs(mean - det["mean"]).max()),
+            log_theta=float(np.abs(lth - det["log_theta"]).max()), z_next=float(np.abs(zg.cpu().numpy() - z_ref).max()),
+            class_ids_differing_above_margin=int((ig.cpu().numpy() != idx_ref)[clear].sum()),
+            fraction_below_margin=float(1.0 - clear.mean()), margin=tol)
+    t = rng.integers(0, T, B)
+    t[0] = 0
+    mo = rng.standard_normal((B, n_num + sumk, L)).astype(np.float32)
+    eps = rng.standard_normal((B, n_num, L)).astype(np.float32)
+    x0i = rng.integers(0, 2, (B, n_cat, L)).astype(np.uint8)
+    xti = rng.integers(0, 2, (B, n_cat, L)).astype(np.uint8)
+    ref = od.mixed_loss(mo, eps, x0i, xti, t, 0.8)
+    loss, grad = diff.mixed_loss(torch.from_numpy(mo).to(dev), torch.from_numpy(eps).to(dev), torch.from_numpy(x0i).to(dev),
+                                 torch.from_numpy(xti).to(dev), torch.from_numpy(t).to(dev), 0.8)
+    gates["loss"] = dict(rel_err=float(abs(loss.item() - ref["loss"]) / abs(ref["loss"])),
+                         grad_rel_err=float(np.abs(grad.cpu().numpy() - ref["grad"]).max() / np.abs(ref["grad"]).max()))
+    gates["sample"] = f"{B} eICU-shaped sequences, L={L}, the bench's weights; tolerances as in tests/test_gpu_parity.py"
+    return gates
+
+
 def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
     """Second half of BASELINE.json's metric: optimizer steps / second of the ETDiff training loop
     (et_diff.py:226-261: ga micro-batches of MixedDiffusion.forward + backward, clip, Adam, EMA) on synthetic
@@ -233,6 +282,11 @@ def main():
     elapsed = agree_max(time.time() - t0)
     assert torch.isfinite(out).all()
     value = world * B * steps_done / elapsed
+    # the boundary's only host transfer, outside the timed region: the decoded (B, C, L) fp32 samples, D2H
+    d0 = time.time()
+    host = out.cpu()
+    d2h_s = agree_max(time.time() - d0)
+    del host
 
     result = None
     if rank == 0:
@@ -269,7 +323,9 @@ def main():
         note(f"roofline probe: {cnt.value} launches, {avg_s * 1e3:.2f} ms each")
         base = None
         if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only: the other ranks would wait on it
-            base = cpu_baseline(sd, cols, L, T, {k: v.numpy() for k, v in tables.items()}, args.cpu_seconds)
+            tabs = {k: v.numpy() for k, v in tables.items()}
+            base = cpu_baseline(sd, cols, L, T, tabs, args.cpu_seconds)
+            base["parity"] = parity_gates(dev, den, diff, sd, cols, L, T, tabs)
         note("cpu baseline done" if base else "cpu baseline skipped")
         train = None
         if world == 1 and not args.no_train_probe:
@@ -289,6 +345,7 @@ def main():
                                    f"3-layer bidirectional LSTM H={H}, T={T}, random-init weights, Philox noise",
                        "batch_per_gpu": B, "sequences_per_step": world * B, "parallelism": f"patient-sharded x{world}",
                        "graph": True},
+            "d2h_s_per_chain": d2h_s, "value_including_d2h": world * B * steps_done / (elapsed + steps_done * d2h_s),
             "denoiser_tflops_whole_chain": value * fl / 1e12,
             "roofline": roofline, "cpu_baseline": base, "train": train,
         }

@@ -1,7 +1,8 @@
 """Quick timing probe of the denoiser forward at the eICU shape (not part of the product)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from timediff_amd.ops import DenoiserKernels
 
 def make_sd(H=256, C=14, N=3, D=2, dev="cuda"):
