@@ -511,7 +511,7 @@ def random_state_small(seed, H=32, C=7, dirs=2):
     return {k_: v.numpy() for k_, v in sd.items()}
 
 
-@pytest.mark.parametrize("n", [1, 37, 600])
+@pytest.mark.parametrize("n", [1, 37, 600, 2048])
 def test_time_film_backward_against_torch(n, dev):
     """td_rnn_time_film_backward (time-embedding MLP + FiLM linear, blocks.py:12-24, :324-329, :285) against torch
     autograd through the same fp32 arithmetic on the CPU (a floating-point kernel: fp32 torch is the reference here);

@@ -14,8 +14,7 @@ static rocblas_handle g_blas = nullptr;
 // nsplit > 1: the contraction index is cut into nsplit equal chunks that run as the batches of ONE strided-batched GEMM,
 // each writing its own M x N partial result (row-major, packed) into `partial`; the caller adds them to C.  With K in
 // the hundreds of thousands and M x N of only a few 256 x 256 tiles this is what fills the chip.
-int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
-                   int nsplit, float *partial, hipStream_t stream) {
+static int td_blas_ready(hipStream_t stream) {
     if (!g_blas) {
         if (rocblas_create_handle(&g_blas) != rocblas_status_success) {
             g_blas = nullptr;
@@ -27,6 +26,30 @@ int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *
         td_set_error("rocblas_set_stream failed");
         return TD_ERR_HIP;
     }
+    return TD_OK;
+}
+
+// dw[r][k] (R x K row-major fp32, accumulated) += sum_i left[i][r] * right[i][k], left / right row-major fp32 with row strides
+// lstride / rstride: the weight gradients of the time-embedding MLP and the FiLM linear over a large batch of rows
+// (rnn.hip: td_rnn_time_film_backward).  Column-major view: dw' (K x R, ld K) = right' (K x n) . left'^T (n x R).
+int td_outer_sum_lib(const float *left, size_t lstride, const float *right, size_t rstride, float *dw, int R, int K, int n,
+                     hipStream_t stream) {
+    int rc = td_blas_ready(stream);
+    if (rc != TD_OK) return rc;
+    const float one = 1.0f;
+    rocblas_status st = rocblas_sgemm(g_blas, rocblas_operation_none, rocblas_operation_transpose, K, R, n, &one, right,
+                                      (rocblas_int)rstride, left, (rocblas_int)lstride, &one, dw, K);
+    if (st != rocblas_status_success) {
+        td_set_error("rocblas_sgemm failed with status %d (R=%d K=%d n=%d)", (int)st, R, K, n);
+        return TD_ERR_HIP;
+    }
+    return TD_OK;
+}
+
+int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
+                   int nsplit, float *partial, hipStream_t stream) {
+    int rc = td_blas_ready(stream);
+    if (rc != TD_OK) return rc;
     const float one = 1.0f, zero = 0.0f;
     if (nsplit > 1) {
         const int kc = K / nsplit;

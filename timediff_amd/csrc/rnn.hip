@@ -341,6 +341,10 @@ __global__ __launch_bounds__(256) void td_time_film_bwd_rows_kernel(TdFilmBwdPar
     for (int k = tid; k < E; k += 256) row[k] = sinus[k];
 }
 
+#define TD_OUTER_LIB_MIN_ROWS 256
+int td_outer_sum_lib(const float *left, size_t lstride, const float *right, size_t rstride, float *dw, int R, int K, int n,
+                     hipStream_t stream);   // gemm_lib.cpp
+
 // d W[r][k] += sum_i left[i][r] * right[i][k]   (left / right: columns of the per-row records, or d film)
 __global__ __launch_bounds__(256) void td_outer_sum_kernel(const float *__restrict__ left, size_t lstride, const float *__restrict__ right,
                                                             size_t rstride, float *__restrict__ dw, int R, int K, int n) {
@@ -377,14 +381,18 @@ extern "C" int td_rnn_time_film_backward(const td_rnn_config *cfg, const float *
     TD_LAUNCH_CHECK();
     const size_t rs = (size_t)E + 4 * T;
     const float *rows = p.rows;
-    // d W_f = d film^T s ; d W_2 = d v2^T a1 ; d W_1 = d v1^T sinus
-    hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(F * T, 256)), dim3(256), 0, stream, grad_film, (size_t)F, rows + E + T, rs, p.d_wf, F, T, n_t);
-    TD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(T * T, 256)), dim3(256), 0, stream, rows + E + 3 * T, rs, rows + E, rs, p.d_w2, T, T, n_t);
-    TD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(T * E, 256)), dim3(256), 0, stream, rows + E + 2 * T, rs, rows, rs, p.d_w1, T, E, n_t);
-    TD_LAUNCH_CHECK();
-    return TD_OK;
+    // d W_f = d film^T s ; d W_2 = d v2^T a1 ; d W_1 = d v1^T sinus.  Over many rows these are plain fp32 GEMMs with the
+    // rows as the contraction index (library, as the recurrent weight gradients); a thread per weight element walking the
+    // rows is enough for the few rows of the reference's batch.
+    auto outer = [&](const float *left, size_t ls, const float *right, float *dw, int R, int K) -> int {
+        if (n_t >= TD_OUTER_LIB_MIN_ROWS) return td_outer_sum_lib(left, ls, right, rs, dw, R, K, n_t, stream);
+        hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(R * K, 256)), dim3(256), 0, stream, left, ls, right, rs, dw, R, K, n_t);
+        TD_LAUNCH_CHECK();
+        return TD_OK;
+    };
+    if ((rc = outer(grad_film, (size_t)F, rows + E + T, p.d_wf, F, T)) != TD_OK) return rc;
+    if ((rc = outer(rows + E + 3 * T, rs, rows + E, p.d_w2, T, T)) != TD_OK) return rc;
+    return outer(rows + E + 2 * T, rs, rows, p.d_w1, T, E);
 }
 
 // ---------------------------------------------------------------------------------------------

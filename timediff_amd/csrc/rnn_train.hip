@@ -624,6 +624,136 @@ __global__ __launch_bounds__(256) void td_frag_gemm_kernel(TdFragGemmParams p) {
     op[64] = b;
 }
 
+// The same product with the weights resident: wave w of a workgroup keeps the NT * KH fragments of row block 4 rbg + w in
+// registers for all the tiles of its chunk, and the input fragments are staged in LDS once per workgroup by LDS-DMA: a
+// ring of 10 stages of KH fragments (one gate slab of one tile, 16 KiB), filled 8 stages = two tiles ahead (HBM latency
+// under load exceeds the time a tile's 64 MFMAs take), read 8 fragments ahead of the MFMAs.  Every input byte is fetched
+// once per group of four row blocks instead of once per row block, and the weights once per workgroup instead of once
+// per tile.  The kernel above re-reads both operands for every MFMA (2 KiB per MFMA and wave: L2-bound, 0.37 PFLOP/s).
+#define TD_FG_STAGES 10
+template <int N, class F>
+__device__ __forceinline__ void td_unrolled(F &&f) {
+    if constexpr (N > 0) {
+        td_unrolled<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int NT, int KH>
+__global__ __launch_bounds__(256, 1) void td_frag_gemm_res_kernel(TdFragGemmParams p, int tiles_per_wg) {
+    constexpr int NK = NT * KH, NSTG = TD_FG_STAGES, LEAD = NSTG - 2, RING = 8, PW = KH / 4;
+    static_assert(KH % 4 == 0 && RING <= KH && NK % RING == 0, "stage / ring geometry");
+    extern __shared__ __attribute__((aligned(16))) char sm[];   // NSTG x KH KiB
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // workgroups go to the XCDs round-robin by index: the rbg workgroups that read the same chunk of tiles sit on ONE XCD
+    // (indices 8 apart), so the chunk comes from HBM once and from that XCD's L2 for the others
+    const int nrbg = (p.nrb + 3) / 4;
+    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int rbg = slot % nrbg, chunk = (slot / nrbg) * 8 + xcd;
+    const int rb0 = rbg * 4 + wave;
+    const int rb = rb0 < p.nrb ? rb0 : p.nrb - 1;      // a wave past the last row block repeats it (and stores nothing)
+    const int t0 = chunk * tiles_per_wg, t1 = min(p.ntiles, t0 + tiles_per_wg);
+    if (t0 >= t1) return;
+    const int nst = (t1 - t0) * NT;                     // stages of this chunk
+    bf16x8 A[NK];
+    {
+        const bf16x8 *wp = (const bf16x8 *)(p.wt + (size_t)rb * NK * TD_FRAG_BYTES) + lane;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) A[i] = wp[i * 64];
+    }
+    // the gate slab of term q, four bits each (an indexed local array would live in scratch memory)
+    unsigned slabs = 0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) slabs |= (unsigned)p.slab[i] << (4 * i);
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)sm;
+    // stage j = gate slab j % NT of tile t0 + j / NT; wave w moves its pieces [w PW, (w + 1) PW).  M0 = LDS base of the
+    // piece (used by nothing else here); issued from inline asm so that the compiler does not drain vmcnt / lgkmcnt at
+    // the next LDS access (rnn_layer.h)
+    auto stage_dma = [&](int j) {
+        const int tile = t0 + j / NT;
+        const int sl = (int)((slabs >> (4 * (j % NT))) & 15u);
+        const char *src = p.in + (p.in_tile_off + (size_t)tile * p.in_frags + (size_t)sl * KH + wave * PW) * TD_FRAG_BYTES;
+        const unsigned dst = lds0 + (unsigned)(((j % NSTG) * KH + wave * PW) * TD_FRAG_BYTES);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const char *sp = src + i * TD_FRAG_BYTES;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + i * TD_FRAG_BYTES), "v"(lane16), "s"(sp) : "memory");
+        }
+    };
+    for (int j = 0; j < LEAD && j < nst; ++j) stage_dma(j);
+    int jr = 0;                   // stage the LDS read pointer enters next
+    const char *rbase = sm;       // base of the stage being read
+    // The read pointer enters stage jr: my pieces of it have landed -- the pieces of the LEAD - 1 stages behind it are
+    // younger (vmcnt retires in order) and stay in flight, output stores in between only make the wait stricter --;
+    // behind the barrier that holds for every wave, and every wave has consumed stage jr - 2, whose buffer the next
+    // pieces go to.
+    auto enter = [&]() {
+        if (jr + LEAD - 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (LEAD - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (jr + LEAD < nst) stage_dma(jr + LEAD);
+        rbase = sm + (size_t)(jr % NSTG) * KH * TD_FRAG_BYTES + lane * 16;
+        ++jr;
+    };
+    bf16x8 bq[RING];
+    enter();
+#pragma unroll
+    for (int i = 0; i < RING; ++i) bq[i] = *(const bf16x8 *)(rbase + i * TD_FRAG_BYTES);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // pinned order: left alone, the scheduler sinks every LDS read next to its MFMA (read -> wait -> MFMA)
+        td_unrolled<NK>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], bq[i % RING], acc, 0, 0, 0);
+            constexpr int r = (i + RING) % NK;          // fragment read now: of this tile, or of the next one
+            if (i + RING < NK || more) {
+                if constexpr (r % KH == 0) enter();
+                bq[i % RING] = *(const bf16x8 *)(rbase + (r % KH) * TD_FRAG_BYTES);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (rb0 < p.nrb) {
+            bf16x8 a, b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = (__bf16)acc[j]; b[j] = (__bf16)acc[8 + j]; }
+            bf16x8 *op = (bf16x8 *)(p.out + ((size_t)t * p.out_frags + p.out_off + 2 * rb) * TD_FRAG_BYTES) + lane;
+            op[0] = a;
+            op[64] = b;
+        }
+    }
+}
+
+template <int NT, int KH>
+static int td_launch_frag_gemm_res(const TdFragGemmParams &q, hipStream_t stream) {
+    const int rbg = td_cdiv(q.nrb, 4);
+    // enough chunks of tiles to give every CU a workgroup, at least four tiles each (the weights are loaded per workgroup)
+    int chunks = td_cdiv(TDC_CUS, rbg);
+    if (chunks > td_cdiv(q.ntiles, 4)) chunks = td_cdiv(q.ntiles, 4);
+    const int per = td_cdiv(q.ntiles, chunks);
+    chunks = td_cdiv(q.ntiles, per);
+    const size_t shm = (size_t)TD_FG_STAGES * KH * TD_FRAG_BYTES;
+    TD_HIP(hipFuncSetAttribute((const void *)td_frag_gemm_res_kernel<NT, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((td_frag_gemm_res_kernel<NT, KH>), dim3(rbg * 8 * td_cdiv(chunks, 8)), dim3(256), shm, stream, q, per);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+static int td_frag_gemm(const TdFragGemmParams &q, hipStream_t stream) {
+    if (q.in_frags == 4 * q.kh && q.kh == 16) {
+        if (q.nterm == 4) return td_launch_frag_gemm_res<4, 16>(q, stream);
+        if (q.nterm == 3) return td_launch_frag_gemm_res<3, 16>(q, stream);
+    }
+    hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(q.nrb, 4), q.ntiles), dim3(256), 0, stream, q);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // BPTT sweep of one layer: the whole time loop in ONE launch.  A workgroup owns one batch block of 32
 // sequences in one direction; wave u (of 8) owns the 32-unit block u: its d c carry and its
@@ -944,8 +1074,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 q.out = ws + t.gout[l - 1][d]; q.out_frags = KT; q.out_off = 0;
                 q.ntiles = L * t.nbb; q.nrb = D * g.nu; q.nterm = G; q.kh = g.kh;
                 q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = 2; q.slab[3] = 3;
-                hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(D * g.nu, 4), L * t.nbb), dim3(256), 0, stream, q);
-                TD_LAUNCH_CHECK();
+                if ((rc = td_frag_gemm(q, stream)) != TD_OK) return rc;
                 // d x is the gradient w.r.t. the DROPPED output of the layer below: the same mask takes it to that output
                 if (td_dropout_p() > 0.f) {
                     rc = td_dropout_apply(ws + t.gout[l - 1][d], t.act_bytes, l - 1, stream);
