@@ -805,6 +805,7 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
         for (int k = 0; k < 4; ++k) { dh[i][k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[i][k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     // bias gradients = sums of d a over steps and sequences: per lane here, over the 32 sequences at the end
     float dbacc[WIDE ? 1 : 4][16];
+    const unsigned slabs = (unsigned)q.slab[0] | (unsigned)q.slab[1] << 4 | (unsigned)q.slab[2] << 8 | (unsigned)q.slab[3] << 12;
     if constexpr (!WIDE) {
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi)
@@ -897,11 +898,42 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                for (int term = 0; term < q.nterm; ++term) {
-                    const bf16x8 *bp = (const bf16x8 *)(dab + (size_t)q.slab[term] * p.kh * TD_FRAG_BYTES) + lane;
-                    const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
+                if constexpr (WIDE) {
+                    // both operands come from L2 (2 KiB per MFMA): the loads run RING fragment pairs ahead of their MFMA,
+                    // in a pinned order (left to the scheduler, each pair is loaded right before its use and the sweep
+                    // spends its time in L2 latency)
+                    constexpr int RING = UPW > 2 ? 4 : 8;
+                    const int total = q.nterm * p.kh;
+                    auto bfrag = [&](int idx) {
+                        const int term = idx / p.kh, ks = idx - term * p.kh;
+                        const int sl = (int)((slabs >> (4 * term)) & 15u);
+                        return *((const bf16x8 *)(dab + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
+                    };
+                    bf16x8 ra[RING], rb[RING];
+#pragma unroll
+                    for (int j = 0; j < RING; ++j) {
+                        const int idx = j < total ? j : total - 1;
+                        ra[j] = wp[(size_t)idx * 64];
+                        rb[j] = bfrag(idx);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    for (int i0 = 0; i0 < total; i0 += RING) {
+#pragma unroll
+                        for (int j = 0; j < RING; ++j) {
+                            if (i0 + j < total) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[j], rb[j], acc, 0, 0, 0);
+                            const int nx = i0 + j + RING < total ? i0 + j + RING : total - 1;   // the tail re-reads the last pair
+                            ra[j] = wp[(size_t)nx * 64];
+                            rb[j] = bfrag(nx);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+                    for (int term = 0; term < q.nterm; ++term) {
+                        const bf16x8 *bp = (const bf16x8 *)(dab + (size_t)q.slab[term] * p.kh * TD_FRAG_BYTES) + lane;
+                        const bf16x8 *ap = wp + (size_t)term * p.kh * 64;
 #pragma unroll 8
-                    for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
+                        for (int ks = 0; ks < p.kh; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ks * 64], bp[ks * 64], acc, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dh[i][r >> 2][r & 3] = acc[r];

@@ -88,14 +88,29 @@ class EMA(nn.Module):
             return 0.0
         return min(max(1 - (1 + epoch / self.inv_gamma) ** -self.power, 0.0), self.beta)
 
+    def _host_counters(self):
+        """The step counter and the initted flag live in buffers (they are part of the checkpoint's `ema` dict); reading
+        them back every optimizer step would drain the GPU queue, so the host keeps its own copy and only writes the
+        buffers.  A load_state_dict invalidates the copy."""
+        if getattr(self, "_host", None) is None:
+            self._host = [int(self.step.item()), bool(self.initted.item())]
+        return self._host
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._host = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def plan_update(self):
         """Advances the step counter and says what this step does to the EMA weights:
         (mode, decay) with mode 0 = nothing, 1 = copy the online weights, 2 = lerp."""
-        step = int(self.step.item()) + 1
+        host = self._host_counters()
+        host[0] += 1
+        step = host[0]
         self.step.fill_(step)
         if step % self.update_every != 0:
             return 0, 0.0
-        if step <= self.update_after_step or not bool(self.initted.item()):
+        if step <= self.update_after_step or not host[1]:
+            host[1] = True
             self.initted.fill_(True)
             return 1, 0.0
         return 2, self.current_decay(step)
@@ -428,8 +443,11 @@ class ETDiff(nn.Module):
         last_log = self.timer()
         logging.info("********** START TRAINING DIFFUSION MODEL **********")
         with tqdm(initial=self.step, total=self.diff_num_steps, disable=not self.is_main_process) as pbar:
+            pending = None      # the loss is read one step late: the next step is enqueued before the host waits
             while self.step < self.diff_num_steps:
-                total_loss = self.train_step().item()
+                loss = self.train_step()
+                total_loss = (pending if pending is not None else loss).item()
+                pending = loss
                 pbar.set_description(f"loss: {total_loss:.4f}")
                 if exists(self.wandb) and self.timer() - last_log > 60:
                     self.wandb.log({"total_loss": total_loss})

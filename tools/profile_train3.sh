@@ -8,8 +8,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for cfg in "$@"; do
     set -- $cfg
-    name=b$1
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$name" -- python3 $ROOT/tools/train_probe.py --batch $1 --ga $2 --steps $3 --warmup 1 > "$OUT/probe_$name.json" 2> "$OUT/trace_$name.log" || { echo "trace failed"; tail -5 "$OUT/trace_$name.log"; exit 1; }
+    name=b$1h${4:-256}
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$name" -- python3 $ROOT/tools/train_probe.py --batch $1 --ga $2 --steps $3 --warmup 1 --hidden ${4:-256} > "$OUT/probe_$name.json" 2> "$OUT/trace_$name.log" || { echo "trace failed"; tail -5 "$OUT/trace_$name.log"; exit 1; }
     DB=$(find "$OUT/trace_$name" -name '*.db' | head -1)
     [ -n "$DB" ] && python3 $ROOT/tools/rocpd_stats.py "$DB" > "$OUT/kernel_stats_$name.csv"
     rm -rf "$OUT/trace_$name"
