@@ -494,13 +494,48 @@ __global__ __launch_bounds__(256) void td_state_to_frags_kernel(td_diffusion_con
 struct TdHeadParams {
     const char *act;  // last layer's fragments
     const float *ln_w, *ln_b, *fc_w, *fc_b, *film;
+    const float *ffr;   // MODE 2: per-sequence FiLM in fragment order (td_film_frag_kernel)
     const int32_t *film_row;
     float *y;
     int film_rows, B, L, nbb, H, hpad, kh, dirs, c_out;
 };
 
-template <int KT, bool PER_SEQ>
+// Per-sequence FiLM rows (training: every sequence has its own time step) folded with the LayerNorm affine and laid out
+// the way the head kernels read them: [batch block][fragment ks][a | b][lane][8] fp32 with
+//     a = ln_w * (1 + scale_b),   b = ln_b * (1 + scale_b) + shift_b        (0 for padded units and sequences)
+// so a lane's multipliers for a fragment are two 32-byte vectors instead of 16 scattered words of the (B, 2 D H) array,
+// read again at every position.
+__global__ __launch_bounds__(256) void td_film_frag_kernel(const float *__restrict__ film, const float *__restrict__ ln_w,
+                                                           const float *__restrict__ ln_b, float *__restrict__ ffr, int B, int nbb, int H,
+                                                           int kh, int dirs) {
+    const int KT = dirs * kh, DH = dirs * H;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)nbb * KT * 64) return;
+    const int lane = (int)(idx % 64), ks = (int)((idx / 64) % KT), bblk = (int)(idx / ((size_t)64 * KT));
+    const int m = lane & 31, hf = lane >> 5, b = bblk * 32 + m;
+    float a[8], c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int unit = 16 * (ks % kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+        const bool ok = unit < H && b < B;
+        const int feat = (ks / kh) * H + (ok ? unit : 0);
+        const float sc = ok ? film[(size_t)b * 2 * DH + feat] + 1.0f : 0.f, sh = ok ? film[(size_t)b * 2 * DH + DH + feat] : 0.f;
+        // the same roundings as td_head_kernel's MODE 1 (one multiply, one fused multiply-add)
+        a[j] = ok ? __fmul_rn(ln_w[feat], sc) : 0.f;
+        c[j] = ok ? __fmaf_rn(ln_b[feat], sc, sh) : 0.f;
+    }
+    float *o = ffr + (((size_t)bblk * KT + ks) * 2) * 512 + lane * 8;
+    *(f32x4 *)o = f32x4{a[0], a[1], a[2], a[3]};
+    *(f32x4 *)(o + 4) = f32x4{a[4], a[5], a[6], a[7]};
+    *(f32x4 *)(o + 512) = f32x4{c[0], c[1], c[2], c[3]};
+    *(f32x4 *)(o + 516) = f32x4{c[4], c[5], c[6], c[7]};
+}
+
+// MODE 0: one FiLM row for the whole batch (the sampler); 1: one row per sequence, read from the (B, 2 D H) array;
+// 2: one row per sequence, read from the fragment-ordered copy above (the training forward)
+template <int KT, int MODE>
 __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
+    constexpr bool PER_SEQ = MODE != 0;
     // [KT][hi|lo] fc_w A-fragments, then three [KT*16] fp32 vectors in fragment order (k = 8 hf + j)
     __shared__ __attribute__((aligned(16))) char hl[KT * 2 * TD_FRAG_BYTES + 3 * KT * 16 * sizeof(float)];
     char *wfr = hl;
@@ -535,10 +570,16 @@ __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
-    const size_t ntask = (size_t)p.L * p.nbb;
+    // MODE 2: the batch blocks are dealt to the XCDs (workgroups go round-robin by index), so a block's 4 KT KiB of FiLM
+    // fragments are fetched into ONE L2 and re-read there at every position
+    const int xcd = MODE == 2 ? blockIdx.x % 8 : 0, xstep = MODE == 2 ? 8 : 1;
+    const int nbx = MODE == 2 ? (p.nbb - xcd + 7) / 8 : p.nbb;            // batch blocks this workgroup draws from
+    const size_t ntask = (size_t)p.L * nbx;
+    const size_t first = (size_t)(blockIdx.x / xstep) * 4 + wave, stride = (size_t)(gridDim.x / xstep) * 4;
 #pragma unroll 1
-    for (size_t task = (size_t)blockIdx.x * 4 + wave; task < ntask; task += (size_t)gridDim.x * 4) {
-        const int l = (int)(task / p.nbb), bblk = (int)(task % p.nbb);
+    for (size_t tx = first; tx < ntask; tx += stride) {
+        const int l = (int)(tx / nbx), bblk = xcd + xstep * (int)(tx % nbx);
+        const size_t task = (size_t)l * p.nbb + bblk;
         const int b = bblk * 32 + m;
         const float *filmb = p.film + (size_t)(b < p.B ? b : 0) * 2 * DH;
         const bf16x8 *fp = (const bf16x8 *)(p.act + task * KT * TD_FRAG_BYTES) + lane;
@@ -579,21 +620,28 @@ __global__ __launch_bounds__(256, 2) void td_head_kernel(TdHeadParams p) {
         for (int ks = 0; ks < KT; ++ks) asm volatile("" : "+v"(v[ks]));
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
-            const f32x4 a0 = *(const f32x4 *)(va + ks * 16), a1 = *(const f32x4 *)(va + ks * 16 + 4);
-            const f32x4 b0 = *(const f32x4 *)(vb + ks * 16), b1 = *(const f32x4 *)(vb + ks * 16 + 4);
+            f32x4 a0, a1, b0, b1;
+            if constexpr (MODE == 2) {
+                const f32x4 *fa = (const f32x4 *)(p.ffr + (((size_t)bblk * KT + ks) * 2) * 512) + lane * 2;
+                a0 = fa[0]; a1 = fa[1]; b0 = fa[128]; b1 = fa[129];
+            } else {
+                a0 = *(const f32x4 *)(va + ks * 16); a1 = *(const f32x4 *)(va + ks * 16 + 4);
+                b0 = *(const f32x4 *)(vb + ks * 16); b1 = *(const f32x4 *)(vb + ks * 16 + 4);
+            }
             bf16x8 yh, yl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float av = j < 4 ? a0[j & 3] : a1[j & 3], bv = j < 4 ? b0[j & 3] : b1[j & 3];
-                if constexpr (PER_SEQ) {
+                if constexpr (MODE == 1) {
                     const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
                     const int feat = (ks / p.kh) * p.H + (unit < p.H ? unit : 0);
                     const float sc = filmb[feat] + 1.0f, sh = filmb[DH + feat];  // padded units: av = bv = 0, mask below
                     const float mk = vm[ks * 16 + j];
-                    bv = (bv * sc + sh) * mk;
-                    av = av * sc;
+                    bv = mk != 0.f ? __fmaf_rn(bv, sc, sh) : 0.f;
+                    av = __fmul_rn(av, sc);
                 }
-                const float yv = ((float)v[ks][j] - mu) * rstd * av + bv;
+                // pinned roundings: every MODE gives the same bits for the same multipliers
+                const float yv = __fmaf_rn(__fmul_rn((float)v[ks][j] - mu, rstd), av, bv);
                 const __bf16 h = (__bf16)yv;
                 yh[j] = h;
                 yl[j] = (__bf16)(yv - (float)h);
@@ -857,14 +905,30 @@ static int td_launch_head(const TdHeadParams &p, hipStream_t stream) {
     const size_t ntask = (size_t)p.L * p.nbb;
     int blocks = (int)((ntask + 3) / 4);
     if (blocks > 2048) blocks = 2048;
-    if (!p.film_row && p.film_rows > 1) hipLaunchKernelGGL((td_head_kernel<KT, true>), dim3(blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((td_head_kernel<KT, false>), dim3(blocks), dim3(256), 0, stream, p);
+    if (!p.film_row && p.film_rows > 1) {
+        if (p.ffr) {
+            hipLaunchKernelGGL(td_film_frag_kernel, dim3(td_cdiv(p.nbb * KT * 64, 256)), dim3(256), 0, stream, p.film, p.ln_w, p.ln_b,
+                               (float *)p.ffr, p.B, p.nbb, p.H, p.kh, p.dirs);
+            TD_LAUNCH_CHECK();
+            hipLaunchKernelGGL((td_head_kernel<KT, 2>), dim3(8 * td_cdiv(blocks, 8)), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((td_head_kernel<KT, 1>), dim3(blocks), dim3(256), 0, stream, p);
+        }
+    } else {
+        hipLaunchKernelGGL((td_head_kernel<KT, 0>), dim3(blocks), dim3(256), 0, stream, p);
+    }
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
 
+// film_frags: td_head_film_frag_bytes() of scratch for the fragment-ordered per-sequence FiLM (or NULL: the rows are read
+// from `film` at every position)
+size_t td_head_film_frag_bytes(const TdRnnGeom &g, int batch) {
+    return g.dirs * g.kh > 32 ? 0 : (size_t)td_cdiv(batch, TD_WAVE_BATCH) * g.dirs * g.kh * 4096;
+}
+
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
-                const int32_t *film_row, int batch, int L, float *y, hipStream_t stream) {
+                const int32_t *film_row, int batch, int L, float *y, hipStream_t stream, float *film_frags) {
     TdRnnGeom g;
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
@@ -872,7 +936,7 @@ int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *
     TdHeadParams p;
     p.act = act;
     p.ln_w = misc[TD_LN_W]; p.ln_b = misc[TD_LN_B]; p.fc_w = misc[TD_FC_W]; p.fc_b = misc[TD_FC_B];
-    p.film = film; p.film_row = film_row; p.film_rows = film_rows;
+    p.film = film; p.film_row = film_row; p.film_rows = film_rows; p.ffr = film_frags;
     p.y = y; p.B = batch; p.L = L; p.nbb = td_cdiv(batch, TD_WAVE_BATCH);
     p.H = cfg->hidden; p.hpad = g.hpad; p.kh = g.kh; p.dirs = g.dirs; p.c_out = cfg->c_out;
     switch (g.dirs * g.kh) {
@@ -927,7 +991,7 @@ int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *co
     if (!td_head_fusable(cfg, g, batch, L, film_rows, film_row, chain)) {
         rc = td_rnn_run_layers_ex(cfg, packed, x, batch, L, x0, acts, nullptr, state, stream);
         if (rc != TD_OK) return rc;
-        return td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, film_rows, film_row, batch, L, y, stream);
+        return td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, film_rows, film_row, batch, L, y, stream, nullptr);
     }
     const TdHeadFuse hl = td_head_fuse_layout(cfg, g, batch, L);
     const int top = cfg->layers - 1;

@@ -29,7 +29,8 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
 int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
                    int nsplit, float *partial, hipStream_t stream);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
-                const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
+                const int32_t *film_row, int batch, int L, float *y, hipStream_t stream, float *film_frags);
+size_t td_head_film_frag_bytes(const TdRnnGeom &g, int batch);
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -120,7 +121,7 @@ extern "C" int td_rnn_dropout_mask(const td_rnn_config *cfg, int32_t batch, int3
 // ---------------------------------------------------------------------------------------------
 struct TdTrainLayout {
     int nbb, Bp, cpad;      // batch blocks, padded batch, layer-0 channels padded to 32
-    size_t x0, act[16], save[16], plain[17], plainx[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, dwpart, total;
+    size_t x0, act[16], save[16], plain[17], plainx[17], gout[16][2], daf[16][2], dapl[16][2], dc[2], inbox, chan, g1, dwpart, filmfr, ysave, pq, total;
     size_t act_bytes, save_dir_floats, daf_bytes, dapl_slab_elems, cols;
 };
 
@@ -159,8 +160,12 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
     }
     t.chan = take((size_t)L * t.nbb * (cfg->c_out + 1) * 32 * sizeof(float));   // head backward: g * rstd per channel, mu
     t.g1 = take((size_t)batch * cfg->c_out * sizeof(float));
-    t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));
-    t.dwpart = take(t.cols >= 2 * TD_DW_SPLIT_MIN_K ? TD_DW_PARTIAL_BYTES : 0);   // split-K partial results of the weight-gradient GEMMs   // the cluster BPTT sweep's partial-sum exchange (small batches only)
+    t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));   // the cluster BPTT sweep's partial-sum exchange
+    t.dwpart = take(t.cols >= 2 * TD_DW_SPLIT_MIN_K ? TD_DW_PARTIAL_BYTES : 0);   // split-K partial results of the weight-gradient GEMMs
+    t.filmfr = take(td_head_film_frag_bytes(g, batch));   // per-sequence FiLM in fragment order (head forward / backward)
+    // the MFMA head backward reads the forward's output and two per-sequence tables (td_head_bwd_dh_mfma_kernel)
+    t.ysave = take(td_head_film_frag_bytes(g, batch) ? (size_t)batch * cfg->c_out * L * sizeof(float) : 0);
+    t.pq = take(td_head_film_frag_bytes(g, batch) ? (size_t)batch * cfg->c_out * 2 * sizeof(float) : 0);
     t.total = off;
     return t;
 }
@@ -254,8 +259,11 @@ extern "C" int td_rnn_forward_train(const td_rnn_config *cfg, const void *packed
             TD_LAUNCH_CHECK();
         }
     }
-    rc = td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, batch, nullptr, batch, seq_len, y, stream);
+    rc = td_rnn_head(cfg, misc, acts[cfg->layers - 1], film, batch, nullptr, batch, seq_len, y, stream,
+                     td_head_film_frag_bytes(g, batch) ? (float *)(ws + t.filmfr) : nullptr);
     if (rc != TD_OK) return rc;
+    if (td_head_film_frag_bytes(g, batch))
+        TD_HIP(hipMemcpyAsync(ws + t.ysave, y, (size_t)batch * cfg->c_out * seq_len * sizeof(float), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(td_x_to_plain_kernel, dim3(2048), dim3(256), 0, stream, x, (__bf16 *)(ws + t.plain[0]), batch, cfg->c_in,
                        t.cpad, seq_len, t.Bp);
     TD_LAUNCH_CHECK();
@@ -358,6 +366,8 @@ struct TdHeadBwdParams {
     float *d_film, *d_ln_w, *d_ln_b, *d_fc_w, *d_fc_b;  // accumulated (atomics)
     int B, L, nbb, H, hpad, kh, dirs, c_out;
     int lch, llen;                                // parameter kernel: the steps are cut into lch chunks of llen
+    const float *ffr, *ysave, *fc_b;              // MFMA variant: FiLM fragments (td_film_frag_kernel), the forward's y, fc bias
+    float *pq;                                    // [B][c_out][2]: sum_f W[c][f] a_b[f], sum_f W[c][f] b_b[f]
 };
 
 // sum over the 32 lanes that share bit 5 of the lane id (one half-wave = the 32 sequences of a batch block)
@@ -480,6 +490,194 @@ __global__ __launch_bounds__(256) void td_head_bwd_dh_kernel(TdHeadBwdParams p) 
             op[ks * 64] = o;
         }
     }
+}
+
+// ---- d h through the matrix cores (hidden sizes whose position fits a wave's registers: D * KH <= 32 fragments) ----
+// With the per-sequence multipliers a = ln_w (1 + scale_b), b = ln_b (1 + scale_b) + shift_b (fragment order, left by the
+// forward pass: td_film_frag_kernel) the head is y[c] = sum_f W[c][f] (xhat[f] a[f] + b[f]) + fc_b[c], so
+//     d xhat[f] = a[f] * dyf[f],   dyf = W^T g            one MFMA per 32 features: A = W^T fragments (LDS), B = g (hi + lo)
+//     m1 = mean_f d xhat[f]         = sum_c g[c] P[b][c] / DH,              P[b][c] = sum_f W[c][f] a_b[f]
+//     m2 = mean_f d xhat[f] xhat[f] = sum_c g[c] (y[c] - fc_b[c] - Q[b][c]) / DH,   Q[b][c] = sum_f W[c][f] b_b[f]
+//     d h[f] = rstd (d xhat[f] - m1 - xhat[f] m2)
+// i.e. both LayerNorm means come from per-position quantities the forward pass left (y) and two per-sequence tables, and
+// the position's fragments are read once.  The accumulator of the MFMA holds dyf in exactly the order of the activation
+// fragments (rows 0..15 = fragment 2 fb, rows 16..31 = fragment 2 fb + 1).
+__global__ __launch_bounds__(256) void td_head_pq_kernel(TdHeadBwdParams p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.B * p.c_out) return;
+    const int b = idx / p.c_out, c = idx % p.c_out, KT = p.dirs * p.kh, DH = p.dirs * p.H;
+    const int bblk = b / 32, m = b % 32;
+    float P = 0.f, Q = 0.f;
+    for (int feat = 0; feat < DH; ++feat) {
+        const int d = feat / p.H, unit = feat % p.H, ks = d * p.kh + unit / 16, w = unit % 16;
+        const int hf = (w >> 2) & 1, j = ((w >> 3) << 2) | (w & 3);
+        const float *f = p.ffr + (((size_t)bblk * KT + ks) * 2) * 512 + (hf * 32 + m) * 8 + j;
+        const float wv = p.fc_w[(size_t)c * DH + feat];
+        P = fmaf(wv, f[0], P);
+        Q = fmaf(wv, f[512], Q);
+    }
+    p.pq[(size_t)idx * 2] = P;
+    p.pq[(size_t)idx * 2 + 1] = Q;
+}
+
+template <int KT, int KC>
+__global__ __launch_bounds__(256) void td_head_bwd_dh_mfma_kernel(TdHeadBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char wfr[];   // [KT / 2][KC][hi | lo] A fragments of W^T
+    const int DH = p.dirs * p.H;
+    for (int idx = threadIdx.x; idx < (KT / 2) * KC * 64 * 8; idx += 256) {
+        const int j = idx % 8, ln = (idx / 8) % 64, kc = (idx / 512) % KC, fb = idx / (512 * KC);
+        const int r = ln & 31, hf = ln >> 5, c = 16 * kc + 8 * hf + j;
+        const int ks0 = 2 * fb, d = ks0 / p.kh, unit = 16 * (ks0 % p.kh) + r;
+        const float w = (c < p.c_out && unit < p.H) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
+        const __bf16 hi = (__bf16)w;
+        __bf16 *dst = (__bf16 *)(wfr + (size_t)((fb * KC + kc) * 2) * TD_FRAG_BYTES);
+        dst[ln * 8 + j] = hi;
+        dst[512 + ln * 8 + j] = (__bf16)(w - (float)hi);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hf = lane >> 5;
+    const int CH = p.c_out + 1;
+    // batch blocks dealt to the XCDs as in the forward head (td_head_kernel, MODE 2)
+    const int xcd = blockIdx.x % 8, nbx = (p.nbb - xcd + 7) / 8;
+    const size_t ntask = (size_t)p.L * nbx;
+    for (size_t tx = (size_t)(blockIdx.x / 8) * 4 + wave; tx < ntask; tx += (size_t)(gridDim.x / 8) * 4) {
+        const int l = (int)(tx / nbx), bblk = xcd + 8 * (int)(tx % nbx);
+        const size_t task = (size_t)l * p.nbb + bblk;
+        const int b = bblk * 32 + m;
+        const bool valid = b < p.B;
+        const bf16x8 *fp = (const bf16x8 *)(p.act + task * KT * TD_FRAG_BYTES) + lane;
+        bf16x8 v[KT];
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) v[ks] = fp[ks * 64];
+        // this lane's channels: c = 16 kc + 8 hf + j
+        float g[KC][8];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * kc + 8 * hf + j;
+                const bool ok = valid && c < p.c_out;
+                const size_t at = ((size_t)(ok ? b : 0) * p.c_out + (ok ? c : 0)) * p.L + l;
+                g[kc][j] = ok ? p.gy[at] : 0.f;
+                if (ok) {
+                    const float *pq = p.pq + ((size_t)b * p.c_out + c) * 2;
+                    m1 = fmaf(g[kc][j], pq[0], m1);
+                    m2 = fmaf(g[kc][j], p.ysave[at] - p.fc_b[c] - pq[1], m2);
+                }
+            }
+        m1 += __shfl_xor(m1, 32);
+        m2 += __shfl_xor(m2, 32);
+        m1 /= (float)DH;
+        m2 /= (float)DH;
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)v[ks][j];
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum / (float)DH;
+        float sq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            const int unit0 = 16 * (ks % p.kh) + 4 * hf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = (float)v[ks][j] - mu;
+                sq += (unit0 + 8 * (j >> 2) + (j & 3)) < p.H ? dlt * dlt : 0.f;
+            }
+        }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq / (float)DH + 1e-5f);
+        {   // what the parameter kernel reads: g[c] * rstd per channel, then mu
+            float *cp = p.chan + task * CH * 32 + m;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * kc + 8 * hf + j;
+                    if (c < p.c_out) cp[c * 32] = g[kc][j] * rstd;
+                }
+            if (hf == 0) cp[p.c_out * 32] = mu;
+        }
+        bf16x8 gh[KC], gl[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 h = (__bf16)g[kc][j];
+                gh[kc][j] = h;
+                gl[kc][j] = (__bf16)(g[kc][j] - (float)h);
+            }
+        bf16x8 *op = (bf16x8 *)(p.gout + task * KT * TD_FRAG_BYTES) + lane;
+        const char *wf = wfr + lane * 16;
+#pragma unroll
+        for (int fb = 0; fb < KT / 2; ++fb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const bf16x8 wh = *(const bf16x8 *)(wf + (size_t)((fb * KC + kc) * 2) * TD_FRAG_BYTES);
+                const bf16x8 wl = *(const bf16x8 *)(wf + (size_t)((fb * KC + kc) * 2 + 1) * TD_FRAG_BYTES);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, gh[kc], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, gl[kc], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, gh[kc], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int ks = 2 * fb + half;
+                const f32x4 *fa = (const f32x4 *)(p.ffr + (((size_t)bblk * KT + ks) * 2) * 512) + lane * 2;
+                const f32x4 a0 = fa[0], a1 = fa[1];
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int unit = 16 * (ks % p.kh) + 8 * (j >> 2) + 4 * hf + (j & 3);
+                    const float xh = ((float)v[ks][j] - mu) * rstd;
+                    const float dxh = acc[8 * half + j] * (j < 4 ? a0[j & 3] : a1[j & 3]);
+                    o[j] = (__bf16)((valid && unit < p.H) ? rstd * (dxh - m1 - xh * m2) : 0.f);
+                }
+                op[ks * 64] = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keeps the FiLM loads of later blocks from being hoisted (register pressure)
+        }
+    }
+}
+
+template <int KT>
+static int td_launch_head_bwd_mfma(const TdHeadBwdParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(td_head_pq_kernel, dim3(td_cdiv(p.B * p.c_out, 256)), dim3(256), 0, stream, p);
+    TD_LAUNCH_CHECK();
+    const size_t ntask = (size_t)p.L * p.nbb;
+    int blocks = (int)((ntask + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    blocks = 8 * td_cdiv(blocks, 8);
+    if (p.c_out <= 16) {
+        const size_t shm = (size_t)(KT / 2) * 2 * TD_FRAG_BYTES;
+        TD_HIP(hipFuncSetAttribute((const void *)td_head_bwd_dh_mfma_kernel<KT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL((td_head_bwd_dh_mfma_kernel<KT, 1>), dim3(blocks), dim3(256), shm, stream, p);
+    } else {
+        const size_t shm = (size_t)(KT / 2) * 4 * TD_FRAG_BYTES;
+        TD_HIP(hipFuncSetAttribute((const void *)td_head_bwd_dh_mfma_kernel<KT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL((td_head_bwd_dh_mfma_kernel<KT, 2>), dim3(blocks), dim3(256), shm, stream, p);
+    }
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+static int td_head_bwd_mfma(const TdHeadBwdParams &p, hipStream_t stream) {
+    switch (p.dirs * p.kh) {
+        case 2: return td_launch_head_bwd_mfma<2>(p, stream);
+        case 4: return td_launch_head_bwd_mfma<4>(p, stream);
+        case 6: return td_launch_head_bwd_mfma<6>(p, stream);
+        case 8: return td_launch_head_bwd_mfma<8>(p, stream);
+        case 12: return td_launch_head_bwd_mfma<12>(p, stream);
+        case 16: return td_launch_head_bwd_mfma<16>(p, stream);
+        case 24: return td_launch_head_bwd_mfma<24>(p, stream);
+        case 32: return td_launch_head_bwd_mfma<32>(p, stream);
+    }
+    td_set_error("head backward: %d fragments per position have no MFMA variant", p.dirs * p.kh);
+    return TD_ERR_UNSUPPORTED;
 }
 
 // G1[row] = sum of the row's L entries (rows = B * c_out rows of grad_y), one wave per row
@@ -1212,8 +1410,15 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
         };
         const int cm = cfg->c_out <= 16 ? 16 : 32;
         const size_t shm = (size_t)(1 + cm) * DHP * sizeof(float);
-        if (shm <= lds_max) rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, false>, shm) : launch(td_head_bwd_dh_kernel<32, false>, shm);
-        else rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, true>, 0) : launch(td_head_bwd_dh_kernel<32, true>, 0);
+        if (td_head_film_frag_bytes(g, batch)) {      // D * KH <= 32 fragments per position: d h on the matrix cores
+            p.ffr = (const float *)(ws + t.filmfr); p.ysave = (const float *)(ws + t.ysave); p.fc_b = misc[TD_FC_B];
+            p.pq = (float *)(ws + t.pq);
+            rc = td_head_bwd_mfma(p, stream);
+        } else if (shm <= lds_max) {
+            rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, false>, shm) : launch(td_head_bwd_dh_kernel<32, false>, shm);
+        } else {
+            rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, true>, 0) : launch(td_head_bwd_dh_kernel<32, true>, 0);
+        }
         if (rc != TD_OK) return rc;
         const int rows = batch * cfg->c_out;
         hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, stream, grad_y, p.g1, rows, L);
