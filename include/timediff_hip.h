@@ -14,8 +14,8 @@
  *     native layout (LSTM gate rows i,f,g,o; GRU gate rows r,z,n);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
  *     enqueues work and takes its scratch through the `workspace` arguments sized by the matching
- *     *_bytes() query.  Exceptions, each once per process: td_rnn_backward[_cb] creates a rocBLAS handle
- *     (which owns a device workspace) on its first call; td_sample_chain instantiates and caches a
+ *     *_bytes() query.  Exceptions, each once per process: td_rnn_backward[_cb], td_cls_backward and (from 256 rows
+ *     up) td_rnn_time_film_backward create a rocBLAS handle (which owns a device workspace) on the first such call; td_sample_chain instantiates and caches a
  *     hipGraph (released by td_sample_chain_release); td_profile_enable creates HIP events;
  *   - limits of this build: hidden <= 1024, c_in <= 32, c_out <= 32, at most TD_MAX_CAT discrete variables
  *     of at most TD_MAX_CLASSES classes each (the reference accepts any K_i, mixed_diffusion.py:44-51);
