@@ -991,7 +991,17 @@ template <int UPW, bool WIDE>
 __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const TdBpttParams &p = q.b;
-    const int bblk = blockIdx.x, d = blockIdx.y;
+    // WIDE, two directions: a 1-D grid dealt so that XCDs 0-3 work direction 0 and XCDs 4-7 direction 1 (workgroups go to
+    // the XCDs round-robin by index): an XCD's 4 MiB L2 then holds ONE direction's W_hh^T (2 MiB at H = 512) instead of both
+    int bblk = blockIdx.x, d = blockIdx.y;
+    if constexpr (WIDE) {
+        if (gridDim.y == 1 && p.dirs == 2) {
+            const int xcd = blockIdx.x % 8;
+            d = xcd / 4;
+            bblk = (blockIdx.x / 8) * 4 + xcd % 4;
+            if (bblk >= p.nbb) return;
+        }
+    }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, m = lane & 31;
     const size_t stage_bytes = (size_t)4 * p.kh * TD_FRAG_BYTES;
     const size_t cols = (size_t)p.L * p.nbb * 32;
@@ -1289,9 +1299,9 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
                 hipLaunchKernelGGL((td_bptt_sweep_kernel<1, false>), dim3(t.nbb, D), dim3(512), shm, stream, q);
             } else if (g.nu <= 16) {
-                hipLaunchKernelGGL((td_bptt_sweep_kernel<2, true>), dim3(t.nbb, D), dim3(512), 0, stream, q);
+                hipLaunchKernelGGL((td_bptt_sweep_kernel<2, true>), D == 2 ? dim3(8 * td_cdiv(t.nbb, 4)) : dim3(t.nbb, 1), dim3(512), 0, stream, q);
             } else {
-                hipLaunchKernelGGL((td_bptt_sweep_kernel<4, true>), dim3(t.nbb, D), dim3(512), 0, stream, q);
+                hipLaunchKernelGGL((td_bptt_sweep_kernel<4, true>), D == 2 ? dim3(8 * td_cdiv(t.nbb, 4)) : dim3(t.nbb, 1), dim3(512), 0, stream, q);
             }
             TD_LAUNCH_CHECK();
         }
