@@ -114,6 +114,14 @@ struct TdClusterParams {
 // each read issued RD MFMAs ahead of its use.  Left to the compiler the reads share one register quad and every MFMA waits
 // for its own ds_read (150 cycles per MFMA instead of 32); the scheduling barriers pin the interleaving.
 #define TDC_RING 8
+template <int N, class F>
+__device__ __forceinline__ void td_cluster_unrolled(F &&f) {
+    if constexpr (N > 0) {
+        td_cluster_unrolled<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+#define TDC_LDS_STATE_BLOCKS 16   // blocks per cluster whose recurrent state fits the LDS left beside the staging buffers
 template <int NF, int W0, int NW>
 __device__ __forceinline__ void tdc_mfma_stream(f32x16 &acc, const bf16x8 (&W)[NW], const bf16x8 *src) {
     constexpr int RD = NF < TDC_RING ? NF : TDC_RING;
@@ -132,7 +140,9 @@ __device__ __forceinline__ void tdc_mfma_stream(f32x16 &acc, const bf16x8 (&W)[N
 // Gate nonlinearities of one (step, batch block) for this lane's 4 units, and everything that leaves the wave:
 // the recurrent state (to the scratch when the cluster works several blocks), h_t as tagged granules for the cluster,
 // h_t as activation fragment for the next layer, the saved gate values for the backward pass.
-template <int NU, bool GRU, bool SAVE>
+// PAYLOAD (the kernel for several blocks per cluster): h_t leaves as untagged 8-byte stores into the parity's 16 KiB of
+// B-fragment-ordered payload at `xch` (the flag that covers it is raised by the caller behind a barrier).
+template <int NU, bool GRU, bool SAVE, bool PAYLOAD = false>
 __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const f32x16 &acc, f32x4 &state, bool dead, float *cptr,
                                                 unsigned long long *xch, unsigned tag0, int s, int l, int bb, int dir, int c, int w,
                                                 int lane) {
@@ -164,7 +174,6 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
             if constexpr (SAVE) { sv[0][i] = rg; sv[1][i] = zg; sv[2][i] = ng; sv[3][i] = acc[12 + i] * (1.0f / P2L2E); sv[4][i] = h; }
         }
     }
-    if (cptr) *(f32x4 *)cptr = state;
     if (dead) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) hval[i] = __builtin_nanf("");
@@ -172,8 +181,16 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
     typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
     bf16x4 hb = {(__bf16)hval[0], (__bf16)hval[1], (__bf16)hval[2], (__bf16)hval[3]};
     const unsigned long long hbits = *(const unsigned long long *)&hb;
-    // publish: two granules per lane, tag = (epoch, s + 1)
-    if (s + 1 < p.L) {
+    if constexpr (PAYLOAD) {
+        // the payload goes out FIRST: the caller's counted wait lets the stores below stay in flight (TDC_STORES_BEHIND_PAYLOAD)
+        if (s + 1 < p.L)
+            __hip_atomic_store((unsigned long long *)((char *)xch + (size_t)(2 * c + (w >> 1)) * TD_FRAG_BYTES + lane * 16 + 8 * (w & 1)), hbits,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+    }
+    if (cptr) *(f32x4 *)cptr = state;
+    if constexpr (PAYLOAD) {
+    } else if (s + 1 < p.L) {   // publish: two granules per lane, tag = (epoch, s + 1)
         unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + ((size_t)(c * TDC_WAVES + w) * 64 + lane) * 2;
         const unsigned tag = tag0 | (unsigned)(s + 1);
 #ifndef TDC_DBG_PLAINSTORE
@@ -329,18 +346,26 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
 }
 
 // The same cluster, working SEVERAL batch blocks per step (batches beyond one block per cluster): block j's h_{s-1} was
-// published a whole round of blocks ago, so everything an iteration needs from memory (granules, input fragments,
-// recurrent state) is fetched one iteration ahead, under the previous block's 48 MFMAs, and one barrier per iteration
-// orders the double-buffered LDS staging.
+// published a whole round of blocks ago, so an iteration's operands are brought in during the iteration before it -- by
+// LDS-DMA straight into the other half of the double-buffered LDS staging, not through registers: the first version held
+// the prefetched granules and input fragments in registers, the compiler had to park them in the accumulator file to make
+// room for the MFMA phase, and that move waited for the loads right after issuing them (4 100 of 11 600 cycles per
+// iteration).  The hand-off is therefore the bandwidth form (rnn_cluster_bwd.hip): h_t as untagged payload in B-fragment
+// order (16 KiB per block and parity, 8-byte write-through stores), one flag word per (block, parity, source workgroup)
+// = (launch epoch, step), raised by one lane behind the NEXT iteration's barrier, i.e. after every wave's
+// `s_waitcnt vmcnt(0)`; the receiver polls the 8 flags and then lets the DMA (sc1 loads) move the payload.
+// A cluster left with ONE block (the batch does not fill the last round) is its own next consumer: it raises the flags
+// and stages the next step behind the step's own stores instead.
 template <int NU, int XF, bool L0, bool GRU, bool SAVE>
 __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterParams p) {
     constexpr int KH = 2 * NU;
     constexpr int NFR = KH + XF;
-    constexpr int XSTAGE = L0 ? XF : XF;             // input fragments staged in LDS per iteration (layer 0: its hi / lo pairs)
-    constexpr int NPOLL = NU * TDC_WAVES * 64 * 2 / 256;
-    constexpr int XLOAD = (XSTAGE + TDC_WAVES - 1) / TDC_WAVES;
-    __shared__ __attribute__((aligned(16))) char lds[2 * KH * TD_FRAG_BYTES + 2 * XSTAGE * TD_FRAG_BYTES];
+    constexpr int HP = KH / TDC_WAVES;                 // payload pieces each wave moves per iteration
+    static_assert(KH % TDC_WAVES == 0, "payload pieces must split over the waves");
+    // [h: 2 x KH KiB][x: 2 x XF KiB][recurrent state: a block's 256 threads x 16 B, for up to TDC_LDS_STATE_BLOCKS blocks]
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     char *hbuf = lds, *xbuf = lds + 2 * KH * TD_FRAG_BYTES;
+    f32x4 *state_lds = (f32x4 *)(lds + 2 * (KH + XF) * TD_FRAG_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,81 +387,130 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
     bf16x8 W[NFR];
 #pragma unroll
     for (int f = 0; f < NFR; ++f) W[f] = *((const bf16x8 *)(wsl + 4096 + (size_t)f * TD_FRAG_BYTES) + lane);
+    // The compiler counts vector-memory operations to place its waits and does not see the LDS-DMA pieces issued from inline
+    // asm below: with these loads still "pending" at the loop header it waits with small counts inside the MFMA phase, i.e.
+    // for the DMA pieces in flight.  Passing the registers through an empty asm makes it wait for them here, once.
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) asm volatile("" : "+v"(W[f]));
+    asm volatile("" : "+v"(bias));
 
     const unsigned tag0 = p.epoch << 12;
     bool dead = false;
+    const bool st_lds = nblk <= TDC_LDS_STATE_BLOCKS;      // the blocks' recurrent state between their steps: LDS, else L2
     auto xrow = [&](int l, int bb) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
-    auto xchp = [&](int bb) { return p.xch + ((size_t)(dir * p.nbb + bb) * 2) * (NU * TDC_WAVES * 128); };
+    // a block's exchange region (64 KiB): payload of parity 0, of parity 1 (KH KiB each), then [parity][source] flag words
+    auto region = [&](int bb) { return (char *)(p.xch + ((size_t)(dir * p.nbb + bb) * 2) * (NU * TDC_WAVES * 128)); };
+    auto flags = [&](int bb, int par) { return (unsigned *)(region(bb) + 2 * KH * TD_FRAG_BYTES) + par * NU; };
     auto cstp = [&](int bb) { return p.cstate + ((((size_t)(dir * p.nbb + bb) * NU + c) * TDC_WAVES + w) * 64 + lane) * 4; };
 
-    // what the NEXT iteration needs, fetched during the current one
-    bf16x8 xpre[XLOAD];
-    unsigned long long gr[NPOLL];
-    f32x4 st_pre = {0.f, 0.f, 0.f, 0.f};
-    auto prefetch = [&](int s2, int l2, int bb2) {
-        const bf16x8 *xp = (const bf16x8 *)xrow(l2, bb2) + lane;
-#pragma unroll
-        for (int i = 0; i < XLOAD; ++i)
-            if (w + TDC_WAVES * i < XSTAGE) xpre[i] = xp[(size_t)(w + TDC_WAVES * i) * 64];
-        if (s2 > 0) {
-            const unsigned long long *src = xchp(bb2) + (size_t)((s2 + 1) & 1) * (NU * TDC_WAVES * 128);
-#ifndef TDC_DBG_NOPOLL
-#pragma unroll
-            for (int n = 0; n < NPOLL; ++n) gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-#pragma unroll
-            for (int n = 0; n < NPOLL; ++n) gr[n] = ((unsigned long long)(tag0 | (unsigned)s2) << 32) | 0x3c003c00u;
-#endif
-            if (nblk > 1) st_pre = *(const f32x4 *)cstp(bb2);   // a single block's state stays in registers (below)
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    // LDS-DMA pieces of 1 KiB (M0 = LDS base of the piece; used by nothing else here); issued from inline asm, covered by
+    // the full wait at the top of every iteration
+    auto dma = [&](const char *src, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lane16), "s"(src) : "memory");
+    };
+    auto dma_sc1 = [&](const char *src, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(dst), "v"(lane16), "s"(src) : "memory");
+    };
+    // Staging of iteration (step s2 at position l2, block bb2) into the LDS halves `par2`: the wave's pieces are the HP payload
+    // pieces of h_{s2-1} (behind the flags) and its share of the XF input fragments.  fpre: the block's flags as read one
+    // iteration earlier (a flag read is an L2 round trip, ~2 000 cycles, even when the flag has long been raised).
+    constexpr int XP = (XF + TDC_WAVES - 1) / TDC_WAVES, NPIECE = HP + XP;
+    auto await_flags = [&](int s2, int bb2, unsigned fpre) {
+        if (s2 <= 0) return;
+        const unsigned *fl = flags(bb2, (s2 - 1) & 1) + (lane & (NU - 1));
+        const unsigned want = tag0 | (unsigned)s2;
+        int spins = 0;
+        unsigned f = fpre;
+        while (!dead) {
+            if (__builtin_amdgcn_ballot_w64(f != want) == 0) break;
+            if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+            if (spins > 1) __builtin_amdgcn_s_sleep(1);
+            f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("" ::: "memory");      // the payload loads stay behind the poll
+    };
+    const char *f_h = nullptr, *f_x = nullptr;    // sources of the staging in progress (wave-uniform)
+    unsigned f_hd = 0, f_xd = 0;
+    bool f_has_h = false;
+    auto stage_begin = [&](int s2, int l2, int bb2, int par2) {
+        f_has_h = s2 > 0;
+        f_h = region(bb2) + (size_t)((s2 + 1) & 1) * KH * TD_FRAG_BYTES + (size_t)w * HP * TD_FRAG_BYTES;
+        f_x = xrow(l2, bb2);
+        asm volatile("" : "+s"(f_h), "+s"(f_x));
+        f_hd = lds0 + (unsigned)((par2 * KH + w * HP) * TD_FRAG_BYTES);
+        f_xd = lds0 + (unsigned)((2 * KH + par2 * XF) * TD_FRAG_BYTES);
+    };
+    auto stage_piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < HP) {
+            if (f_has_h) dma_sc1(f_h + k * TD_FRAG_BYTES, f_hd + k * TD_FRAG_BYTES);
+        } else if constexpr (k < NPIECE) {
+            constexpr int i = k - HP;
+            if (w + TDC_WAVES * i < XF) dma(f_x + (size_t)(w + TDC_WAVES * i) * TD_FRAG_BYTES, f_xd + (w + TDC_WAVES * i) * TD_FRAG_BYTES);
         }
     };
-    prefetch(0, dir ? p.L - 1 : 0, gi);
+    auto fetch = [&](int s2, int l2, int bb2, int par2, unsigned fpre) {
+        await_flags(s2, bb2, fpre);
+        stage_begin(s2, l2, bb2, par2);
+        td_cluster_unrolled<NPIECE>(stage_piece);
+    };
+    fetch(0, dir ? p.L - 1 : 0, gi, 0, 0u);
+    unsigned fnext = 0;     // flags of the iteration after next, read ahead (0 never equals a tag of this launch: epoch >= 1)
+    bool counted = false;   // the iteration before issued exactly TDC_STORES_BEHIND_PAYLOAD stores behind its payload store
 
+    unsigned *pend_flag = nullptr;      // flag of the payload stored in the iteration before, raised behind the next barrier
+    unsigned pend_tag = 0;
+    f32x4 keep = {0.f, 0.f, 0.f, 0.f};  // a single block's recurrent state stays in registers
     int it = 0;
+#ifdef TDC_STAMP
+    // diagnostic build (-DTDC_STAMP): cycles per phase of wave 0 of workgroup 0, printed at the end
+    unsigned long long stp[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime(), st_c0 = st_last;
+#define TDC_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stp[k] += now_ - st_last; st_last = now_; }
+#else
+#define TDC_MARK(k)
+#endif
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
         for (int j = 0; j < nblk; ++j, ++it) {
             const int bb = gi + j * p.ngroups, par = it & 1;
-            unsigned long long *xch = xchp(bb);
-            // A: this iteration's h_{s-1}: normally all there; a slower peer's granules are re-read until their tag matches
-            if (s > 0) {
-                const unsigned long long *src = xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128);
-                const unsigned want = tag0 | (unsigned)s;
-                int spins = 0;
-                while (!dead) {
-                    bool ok = true;
-#pragma unroll
-                    for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
-                    if (ok) break;
-                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                    for (int n = 0; n < NPOLL; ++n)
-                        if ((unsigned)(gr[n] >> 32) != want)
-                            gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int n = 0; n < NPOLL; ++n) {
-                    const int g = tid + 256 * n;
-                    const int e = g & 1, ln = (g >> 1) & 63, wp = (g >> 7) & 3, cp = g >> 9;
-                    *(unsigned *)(hbuf + (size_t)par * KH * TD_FRAG_BYTES + (size_t)(2 * cp + (wp >> 1)) * TD_FRAG_BYTES + ln * 16 +
-                                  8 * (wp & 1) + 4 * e) = (unsigned)gr[n];
-                }
+            TDC_MARK(5)
+            // this iteration's h and x have landed in LDS, and every vector-memory operation of this wave so far has completed --
+            // the payload stores of the iteration before among them; behind the barrier that holds for every wave, and the
+            // other halves of the LDS buffers are free again
+            // (the stores issued behind the payload store are younger -- vmcnt retires in order -- and may stay in flight)
+            if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SAVE ? 6 : 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TDC_MARK(0)
+            __syncthreads();
+            TDC_MARK(1)
+            if (pend_tag) {
+                if (tid == 0) __hip_atomic_store(pend_flag, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend_tag = 0;
             }
-            {
-                bf16x8 *xd = (bf16x8 *)(xbuf + (size_t)par * XSTAGE * TD_FRAG_BYTES) + lane;
-#pragma unroll
-                for (int i = 0; i < XLOAD; ++i)
-                    if (w + TDC_WAVES * i < XSTAGE) xd[(size_t)(w + TDC_WAVES * i) * 64] = xpre[i];
+            f32x4 state = keep;
+            if (nblk > 1 && s > 0) state = st_lds ? state_lds[j * 256 + tid] : *(const f32x4 *)cstp(bb);
+            const bool last_blk = j + 1 == nblk;
+            const int s2 = last_blk ? s + 1 : s, bb2 = last_blk ? gi : bb + p.ngroups;
+            const int l2 = dir ? p.L - 1 - s2 : s2;
+            const bool staging = nblk > 1 && s2 < p.L;
+            if (staging) {
+                await_flags(s2, bb2, fnext);
+                stage_begin(s2, l2, bb2, par ^ 1);
+                // all pieces at once: spread over the input MFMAs (one behind every second MFMA) they stall the MFMA issue for
+                // longer than their address processing takes here (measured: 2 590 -> 4 120 cycles for the MFMA phase)
+                td_cluster_unrolled<NPIECE>(stage_piece);
+                // the flags the iteration after this one will ask for
+                const bool last2 = bb2 + p.ngroups >= p.nbb;
+                const int s3 = last2 ? s2 + 1 : s2, bb3 = last2 ? gi : bb2 + p.ngroups;
+                fnext = (s3 > 0 && s3 < p.L) ? __hip_atomic_load(flags(bb3, (s3 - 1) & 1) + (lane & (NU - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             }
-            f32x4 state = st_pre;
-            __syncthreads();     // h and x of this iteration are in LDS; the other parity's buffers are free again
-            // D: the next iteration's granules, inputs and state
-            if (j + 1 < nblk) prefetch(s, l, bb + p.ngroups);
-            else if (s + 1 < p.L) prefetch(s + 1, dir ? l - 1 : l + 1, gi);
-            // E: input projection + recurrent part
+            TDC_MARK(2)
+            // input projection + recurrent part
             f32x16 acc = bias;
-            const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)par * XSTAGE * TD_FRAG_BYTES) + lane;
+            const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)par * XF * TD_FRAG_BYTES) + lane;
             if constexpr (L0) {
 #pragma unroll
                 for (int kx = 0; kx < XF / 2; ++kx) {
@@ -452,12 +526,37 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
                 const bf16x8 *hs = (const bf16x8 *)(hbuf + (size_t)par * KH * TD_FRAG_BYTES) + lane;
                 tdc_mfma_stream<KH, 0, NFR>(acc, W, hs);
             }
-            // F: gates, state, hand-off, outputs
-            tdc_finish_step<NU, GRU, SAVE>(p, acc, state, dead, nblk > 1 && s + 1 < p.L ? cstp(bb) : nullptr, xch, tag0, s, l, bb, dir, c, w,
-                                           lane);
-            if (nblk == 1) st_pre = state;
+            TDC_MARK(3)
+            // gates, state, payload, outputs
+            char *pay = region(bb) + (size_t)(s & 1) * KH * TD_FRAG_BYTES;
+            tdc_finish_step<NU, GRU, SAVE, true>(p, acc, state, dead, nblk > 1 && !st_lds && s + 1 < p.L ? cstp(bb) : nullptr,
+                                                 (unsigned long long *)pay, tag0, s, l, bb, dir, c, w, lane);
+            if (nblk == 1) keep = state;
+            else if (st_lds) state_lds[j * 256 + tid] = state;
+            counted = nblk > 1 && st_lds && s + 1 < p.L;      // payload, then the output (+ 5 saved quantities)
+            if (s + 1 < p.L) {
+                pend_flag = flags(bb, s & 1) + c;
+                pend_tag = tag0 | (unsigned)(s + 1);
+                if (nblk == 1) {
+                    // the only block: the next iteration consumes these very values
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(pend_flag, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend_tag = 0;
+                    fetch(s2, l2, bb2, par ^ 1, 0u);
+                }
+            }
+            TDC_MARK(4)
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA piece in flight when the workgroup's LDS is handed on
+#ifdef TDC_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+        const unsigned long long cyc = __builtin_amdgcn_s_memtime() - st_c0, rt = __builtin_amdgcn_s_memrealtime() - st_r0;
+        printf("cluster multi XF=%d SAVE=%d: %d iterations, %llu cycles (%.0f MHz); per iteration: wait %llu barrier %llu poll+dma %llu mfma %llu finish %llu loop %llu\n",
+               XF, (int)SAVE, it, cyc, (double)cyc / (double)rt * 100.0, stp[0] / it, stp[1] / it, stp[2] / it, stp[3] / it, stp[4] / it, stp[5] / it);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,12 +596,18 @@ int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, con
 template <int NU, int XF, bool L0>
 static int tdc_launch2(int gru, int save, const TdClusterParams &p, int blocks, hipStream_t stream) {
     if (p.nbb > p.ngroups) {   // some cluster works two or more batch blocks: the pipelined kernel
-        if (!gru && !save) hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, false, false>), dim3(blocks), dim3(256), 0, stream, p);
-        else if (!gru) hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, false, true>), dim3(blocks), dim3(256), 0, stream, p);
-        else if (!save) hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, true, false>), dim3(blocks), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((td_rnn_cluster_multi_kernel<NU, XF, L0, true, true>), dim3(blocks), dim3(256), 0, stream, p);
-        TD_LAUNCH_CHECK();
-        return TD_OK;
+        const int nblk = td_cdiv(p.nbb, p.ngroups);
+        const size_t shm = (size_t)2 * (2 * NU + XF) * TD_FRAG_BYTES + (nblk <= TDC_LDS_STATE_BLOCKS ? (size_t)nblk * 256 * 16 : 0);
+        auto launch = [&](auto kern) -> int {
+            TD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, stream, p);
+            TD_LAUNCH_CHECK();
+            return TD_OK;
+        };
+        if (!gru && !save) return launch(td_rnn_cluster_multi_kernel<NU, XF, L0, false, false>);
+        if (!gru) return launch(td_rnn_cluster_multi_kernel<NU, XF, L0, false, true>);
+        if (!save) return launch(td_rnn_cluster_multi_kernel<NU, XF, L0, true, false>);
+        return launch(td_rnn_cluster_multi_kernel<NU, XF, L0, true, true>);
     }
     if (!gru && !save) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, false, false>), dim3(blocks), dim3(256), 0, stream, p);
     else if (!gru) hipLaunchKernelGGL((td_rnn_cluster_kernel<NU, XF, L0, false, true>), dim3(blocks), dim3(256), 0, stream, p);
