@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
     ap.add_argument("--train-batch", type=int, default=32, help="training probe: batch per micro-batch (reference default 32)")
-    ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--train-steps", type=int, default=100, help="timed optimizer steps of the small-batch training probes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-oracle baseline sample")
     args = ap.parse_args()
 
@@ -331,9 +331,9 @@ def main():
         if world == 1 and not args.no_train_probe:
             del out, z, idx, mo
             torch.cuda.empty_cache()
-            train = {"reference_batch": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 2),
-                     "reference_batch_looped": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 2, fuse=False),
-                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 6, 2)}
+            train = {"reference_batch": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 5),
+                     "reference_batch_looped": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 5, fuse=False),
+                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 12, 2)}
         fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
         result = {
             "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,

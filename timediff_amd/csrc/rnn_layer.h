@@ -33,6 +33,14 @@
 #include "rnn_layout.h"
 #include "rnn_params.h"
 
+// diagnostic (tools/kbench): -DTD_ABLATE_MFMA drops the matrix instructions (what the gate math and the memory side cost
+// alone), -DTD_ABLATE_GATES the nonlinearities
+#ifdef TD_ABLATE_MFMA
+#define TD_MFMA(a, b, c) (c)
+#else
+#define TD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 #include <type_traits>
 
 // gate-math micro-ops a slot may carry, in relative units: a slot that also issues vector-memory
@@ -340,7 +348,13 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             f32x16(&a)[4] = acc[ub & 1];
             float(&t)[6] = T0[r & 1];
             float hval = 0.f;
+#ifdef TD_ABLATE_GATES
+            // diagnostic (tools/kbench): no nonlinearities, h = the first gate's pre-activation -- what the MFMA / LDS / DMA side costs alone
+            if constexpr (o == NOPS - 1) hval = a[0][r];
+            if constexpr (false) {
+#else
             if constexpr (!GRU) {
+#endif
                 // the accumulators arrive pre-multiplied by -log2(e) (i, f, o) / 2 log2(e) (g): td_pack_weights_kernel
                 if constexpr (o == 0) t[0] = __builtin_amdgcn_exp2f(a[0][r]);
                 if constexpr (o == 1) t[1] = __builtin_amdgcn_exp2f(a[1][r]);
@@ -432,27 +446,27 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 f32x16(&ac)[4] = acc[u & 1];
                 if constexpr (f < 4) {
                     // bias k-step (LSTM: b_ih + b_hh per gate; GRU: r, z, n-input, n-hidden)
-                    ac[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, ac[f], 0, 0, 0);
+                    ac[f] = TD_MFMA(a, ones, ac[f]);
                 } else if constexpr (f - 4 < KH * NG) {
                     // recurrent part: h_{t-1} straight from registers
                     constexpr int ks = (f - 4) / NG, g = (f - 4) % NG;
                     constexpr int ai = (GRU && g == 2) ? 3 : g;
-                    ac[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hold[ks], ac[ai], 0, 0, 0);
+                    ac[ai] = TD_MFMA(a, hold[ks], ac[ai]);
                 } else if constexpr (L0) {
                     // first layer: W = Whi + Wlo, x = xhi + xlo in bf16; keep the three leading products
                     constexpr int x = f - 4 - KH * NG;
                     constexpr int part = x & 1, kx = (x >> 1) / NG, g = (x >> 1) % NG;
                     if constexpr (part == 0) {
-                        ac[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[2 * kx + 1], ac[g], 0, 0, 0);
-                        ac[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[2 * kx], ac[g], 0, 0, 0);
+                        ac[g] = TD_MFMA(a, xf[2 * kx + 1], ac[g]);
+                        ac[g] = TD_MFMA(a, xf[2 * kx], ac[g]);
                     } else {
-                        ac[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[2 * kx], ac[g], 0, 0, 0);
+                        ac[g] = TD_MFMA(a, xf[2 * kx], ac[g]);
                     }
                 } else {
                     constexpr int x = f - 4 - KH * NG;
                     constexpr int kx = x / NG, g = x % NG;
                     if constexpr (g == 0 && kx + 1 < KX) xb[(kx + 1) % 2] = xfrag(kx + 1);
-                    ac[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[kx % 2], ac[g], 0, 0, 0);
+                    ac[g] = TD_MFMA(a, xb[kx % 2], ac[g]);
                 }
                 if constexpr (S::refill_of(F) >= 0)
                     A[F % APD] = refill(std::integral_constant<int, (S::refill_of(F) >= 0 ? S::refill_of(F) : 0)>{});
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
                 }
                 const bf16x8 a = A[F % APD];
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hn[f / 2], hacc, 0, 0, 0);
+                hacc = TD_MFMA(a, hn[f / 2], hacc);
                 if constexpr (S::refill_of(F) >= 0)
                     A[F % APD] = refill(std::integral_constant<int, (S::refill_of(F) >= 0 ? S::refill_of(F) : 0)>{});
                 constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];

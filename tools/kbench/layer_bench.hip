@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
     const char *path = argc > 5 ? argv[5] : "/tmp/layer_ref.bin";
     using T = TdLayerTraits<NU_, KX_, L0_, GRU_>;
     const int nbb = (B + 31) / 32, dirs = 2;
-    const size_t dir_bytes = (size_t)((T::NF + TD_STAGE_FRAGS - 1) / TD_STAGE_FRAGS) * TD_STAGE_BYTES;
+    const size_t dir_bytes = (size_t)((T::NF + TD_RING_FRAGS - 1) / TD_RING_FRAGS) * TD_RING_BYTES;
     const int in_frags = T::XFR, out_frags = dirs * T::KH;
     const size_t wbytes = dir_bytes * dirs, xbytes = (size_t)L * nbb * in_frags * TD_FRAG_BYTES, obytes = (size_t)L * nbb * out_frags * TD_FRAG_BYTES;
     std::vector<uint16_t> hw(wbytes / 2), hx(xbytes / 2);
