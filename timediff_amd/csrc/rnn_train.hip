@@ -503,12 +503,13 @@ __global__ __launch_bounds__(256) void td_head_bwd_dh_kernel(TdHeadBwdParams p) 
 // the position's fragments are read once.  The accumulator of the MFMA holds dyf in exactly the order of the activation
 // fragments (rows 0..15 = fragment 2 fb, rows 16..31 = fragment 2 fb + 1).
 __global__ __launch_bounds__(256) void td_head_pq_kernel(TdHeadBwdParams p) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // one wave per (sequence, channel): the lanes split the D H features
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= p.B * p.c_out) return;
     const int b = idx / p.c_out, c = idx % p.c_out, KT = p.dirs * p.kh, DH = p.dirs * p.H;
     const int bblk = b / 32, m = b % 32;
     float P = 0.f, Q = 0.f;
-    for (int feat = 0; feat < DH; ++feat) {
+    for (int feat = lane; feat < DH; feat += 64) {
         const int d = feat / p.H, unit = feat % p.H, ks = d * p.kh + unit / 16, w = unit % 16;
         const int hf = (w >> 2) & 1, j = ((w >> 3) << 2) | (w & 3);
         const float *f = p.ffr + (((size_t)bblk * KT + ks) * 2) * 512 + (hf * 32 + m) * 8 + j;
@@ -516,8 +517,12 @@ __global__ __launch_bounds__(256) void td_head_pq_kernel(TdHeadBwdParams p) {
         P = fmaf(wv, f[0], P);
         Q = fmaf(wv, f[512], Q);
     }
-    p.pq[(size_t)idx * 2] = P;
-    p.pq[(size_t)idx * 2 + 1] = Q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { P += __shfl_xor(P, o); Q += __shfl_xor(Q, o); }
+    if (lane == 0) {
+        p.pq[(size_t)idx * 2] = P;
+        p.pq[(size_t)idx * 2 + 1] = Q;
+    }
 }
 
 template <int KT, int KC>
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(256) void td_head_bwd_dh_mfma_kernel(TdHeadBwdParam
 
 template <int KT>
 static int td_launch_head_bwd_mfma(const TdHeadBwdParams &p, hipStream_t stream) {
-    hipLaunchKernelGGL(td_head_pq_kernel, dim3(td_cdiv(p.B * p.c_out, 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(td_head_pq_kernel, dim3(td_cdiv(p.B * p.c_out, 4)), dim3(256), 0, stream, p);
     TD_LAUNCH_CHECK();
     const size_t ntask = (size_t)p.L * p.nbb;
     int blocks = (int)((ntask + 3) / 4);
