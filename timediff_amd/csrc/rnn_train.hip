@@ -529,9 +529,10 @@ template <int KT, int KC>
 __global__ __launch_bounds__(256) void td_head_bwd_dh_mfma_kernel(TdHeadBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char wfr[];   // [KT / 2][KC][hi | lo] A fragments of W^T
     const int DH = p.dirs * p.H;
+    // (consecutive threads read consecutive features of one channel's row: coalesced; the 2-byte LDS writes scatter instead)
     for (int idx = threadIdx.x; idx < (KT / 2) * KC * 64 * 8; idx += 256) {
-        const int j = idx % 8, ln = (idx / 8) % 64, kc = (idx / 512) % KC, fb = idx / (512 * KC);
-        const int r = ln & 31, hf = ln >> 5, c = 16 * kc + 8 * hf + j;
+        const int r = idx % 32, j = (idx / 32) % 8, hf = (idx / 256) % 2, kc = (idx / 512) % KC, fb = idx / (512 * KC);
+        const int ln = hf * 32 + r, c = 16 * kc + 8 * hf + j;
         const int ks0 = 2 * fb, d = ks0 / p.kh, unit = 16 * (ks0 % p.kh) + r;
         const float w = (c < p.c_out && unit < p.H) ? p.fc_w[(size_t)c * DH + d * p.H + unit] : 0.f;
         const __bf16 hi = (__bf16)w;
@@ -616,8 +617,20 @@ __global__ __launch_bounds__(256) void td_head_bwd_dh_mfma_kernel(TdHeadBwdParam
             }
         bf16x8 *op = (bf16x8 *)(p.gout + task * KT * TD_FRAG_BYTES) + lane;
         const char *wf = wfr + lane * 16;
+        // the FiLM multipliers of block fb + 1 are fetched while block fb is worked (the blocks are pinned in order, below)
+        f32x4 am[2][2][2];
+        auto load_a = [&](int fb, f32x4 (&dst)[2][2]) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 *fa = (const f32x4 *)(p.ffr + (((size_t)bblk * KT + 2 * fb + half) * 2) * 512) + lane * 2;
+                dst[half][0] = fa[0];
+                dst[half][1] = fa[1];
+            }
+        };
+        load_a(0, am[0]);
 #pragma unroll
         for (int fb = 0; fb < KT / 2; ++fb) {
+            if (fb + 1 < KT / 2) load_a(fb + 1, am[(fb + 1) & 1]);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -632,8 +645,7 @@ __global__ __launch_bounds__(256) void td_head_bwd_dh_mfma_kernel(TdHeadBwdParam
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int ks = 2 * fb + half;
-                const f32x4 *fa = (const f32x4 *)(p.ffr + (((size_t)bblk * KT + ks) * 2) * 512) + lane * 2;
-                const f32x4 a0 = fa[0], a1 = fa[1];
+                const f32x4 a0 = am[fb & 1][half][0], a1 = am[fb & 1][half][1];
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
