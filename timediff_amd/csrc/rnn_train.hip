@@ -1008,6 +1008,10 @@ template <int UPW, bool WIDE>
 __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const TdBpttParams &p = q.b;
+    // up to 16 unit blocks (hidden <= 512) d a_t (4 KH KiB <= 128 KiB) also fits LDS, single-buffered with a second barrier per
+    // step: the recurrent product then reads its B operand there instead of back from L2 (half the L2 traffic of the
+    // product, no fence)
+    constexpr bool LDSB = WIDE && UPW == 2;
     // WIDE, two directions: a 1-D grid dealt so that XCDs 0-3 work direction 0 and XCDs 4-7 direction 1 (workgroups go to
     // the XCDs round-robin by index): an XCD's 4 MiB L2 then holds ONE direction's W_hh^T (2 MiB at H = 512) instead of both
     int bblk = blockIdx.x, d = blockIdx.y;
@@ -1103,6 +1107,7 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                     }
                     *((bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
                     if constexpr (!WIDE) *((bf16x8 *)(dab + ((size_t)gi * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
+                    if constexpr (LDSB) *((bf16x8 *)(sm + ((size_t)gi * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
                     __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                 }
             }
         }
-        if constexpr (WIDE) __threadfence();   // the fragments must be in L2 before another wave reads them back
+        if constexpr (WIDE && !LDSB) __threadfence();   // the fragments must be in L2 before another wave reads them back
         __syncthreads();   // d a_t of every unit block is published (LDS: the other buffer is free again two steps on)
         if (s + 1 < p.L) {
 #pragma unroll
@@ -1132,7 +1137,8 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                     auto bfrag = [&](int idx) {
                         const int term = idx / p.kh, ks = idx - term * p.kh;
                         const int sl = (int)((slabs >> (4 * term)) & 15u);
-                        return *((const bf16x8 *)(dab + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
+                        if constexpr (LDSB) return *((const bf16x8 *)(sm + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
+                        else return *((const bf16x8 *)(dab + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
                     };
                     bf16x8 ra[RING], rb[RING];
 #pragma unroll
@@ -1164,6 +1170,7 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                 for (int r = 0; r < 16; ++r) dh[i][r >> 2][r & 3] = acc[r];
             }
         }
+        if constexpr (LDSB) __syncthreads();   // every wave has read d a_t: the single LDS copy may be overwritten
     }
     if constexpr (!WIDE) {
         if (w < p.nu) {
@@ -1316,7 +1323,9 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
                 hipLaunchKernelGGL((td_bptt_sweep_kernel<1, false>), dim3(t.nbb, D), dim3(512), shm, stream, q);
             } else if (g.nu <= 16) {
-                hipLaunchKernelGGL((td_bptt_sweep_kernel<2, true>), D == 2 ? dim3(8 * td_cdiv(t.nbb, 4)) : dim3(t.nbb, 1), dim3(512), 0, stream, q);
+                const size_t shm = (size_t)4 * g.kh * TD_FRAG_BYTES;
+                TD_HIP(hipFuncSetAttribute((const void *)td_bptt_sweep_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL((td_bptt_sweep_kernel<2, true>), D == 2 ? dim3(8 * td_cdiv(t.nbb, 4)) : dim3(t.nbb, 1), dim3(512), shm, stream, q);
             } else {
                 hipLaunchKernelGGL((td_bptt_sweep_kernel<4, true>), D == 2 ? dim3(8 * td_cdiv(t.nbb, 4)) : dim3(t.nbb, 1), dim3(512), 0, stream, q);
             }
