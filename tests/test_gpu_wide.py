@@ -99,6 +99,7 @@ def test_wide_sample_chain_matches_stepwise(dev):
 # (H, layers, dirs, gru, C, n_num, B, L)
 WIDE_TRAIN = [
     (512, 2, 2, 0, 14, 4, 37, 8),     # bidirectional, head backward with parameters in LDS
+    (512, 3, 2, 1, 9, 7, 70, 6),      # GRU at 16 unit blocks: the three-term resident-weight d x GEMM, three batch blocks
     (320, 2, 2, 1, 9, 7, 33, 6),      # GRU, padded unit blocks
     (1024, 2, 2, 0, 9, 7, 20, 5),     # D*H = 2048, 4 unit blocks per sweep wave
     (768, 2, 1, 0, 23, 7, 5, 6),      # c_out > 16

@@ -854,27 +854,31 @@ __device__ __forceinline__ void td_unrolled(F &&f) {
     }
 }
 
-template <int NT, int KH>
+// KS = 2 (hidden sizes whose NT * KH fragments per row block exceed a wave's registers: KH = 32): two waves share a row
+// block, each holding the weight fragments of one half of every gate slab's k-steps and reading only that half of a stage;
+// the odd wave hands its accumulator to the even one through LDS at the end of a tile.  NSTG: ring stages (KH KiB each).
+template <int NT, int KH, int KS, int NSTG>
 __global__ __launch_bounds__(256, 1) void td_frag_gemm_res_kernel(TdFragGemmParams p, int tiles_per_wg) {
-    constexpr int NK = NT * KH, NSTG = TD_FG_STAGES, LEAD = NSTG - 2, RING = 8, PW = KH / 4;
-    static_assert(KH % 4 == 0 && RING <= KH && NK % RING == 0, "stage / ring geometry");
-    extern __shared__ __attribute__((aligned(16))) char sm[];   // NSTG x KH KiB
+    constexpr int KHL = KH / KS, NK = NT * KHL, LEAD = NSTG - 2, RING = 8, PW = KH / 4, RBG = 4 / KS;
+    static_assert(KH % 4 == 0 && KH % KS == 0 && RING <= KHL && NK % RING == 0 && (KS == 1 || KS == 2), "stage / ring geometry");
+    extern __shared__ __attribute__((aligned(16))) char sm[];   // NSTG x KH KiB (+ 2 x 4 KiB of accumulators, KS = 2)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int kh_half = wave % KS;                      // which half of the k-steps this wave multiplies
     // workgroups go to the XCDs round-robin by index: the rbg workgroups that read the same chunk of tiles sit on ONE XCD
     // (indices 8 apart), so the chunk comes from HBM once and from that XCD's L2 for the others
-    const int nrbg = (p.nrb + 3) / 4;
+    const int nrbg = (p.nrb + RBG - 1) / RBG;
     const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int rbg = slot % nrbg, chunk = (slot / nrbg) * 8 + xcd;
-    const int rb0 = rbg * 4 + wave;
+    const int rb0 = rbg * RBG + wave / KS;
     const int rb = rb0 < p.nrb ? rb0 : p.nrb - 1;      // a wave past the last row block repeats it (and stores nothing)
     const int t0 = chunk * tiles_per_wg, t1 = min(p.ntiles, t0 + tiles_per_wg);
     if (t0 >= t1) return;
     const int nst = (t1 - t0) * NT;                     // stages of this chunk
     bf16x8 A[NK];
     {
-        const bf16x8 *wp = (const bf16x8 *)(p.wt + (size_t)rb * NK * TD_FRAG_BYTES) + lane;
+        const bf16x8 *wp = (const bf16x8 *)(p.wt + (size_t)rb * NT * KH * TD_FRAG_BYTES) + lane;
 #pragma unroll
-        for (int i = 0; i < NK; ++i) A[i] = wp[i * 64];
+        for (int i = 0; i < NK; ++i) A[i] = wp[(size_t)((i / KHL) * KH + kh_half * KHL + i % KHL) * 64];
     }
     // the gate slab of term q, four bits each (an indexed local array would live in scratch memory)
     unsigned slabs = 0;
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(256, 1) void td_frag_gemm_res_kernel(TdFragGemmPara
     };
     for (int j = 0; j < LEAD && j < nst; ++j) stage_dma(j);
     int jr = 0;                   // stage the LDS read pointer enters next
-    const char *rbase = sm;       // base of the stage being read
+    const char *rbase = sm;       // this wave's fragments of the stage being read
     // The read pointer enters stage jr: my pieces of it have landed -- the pieces of the LEAD - 1 stages behind it are
     // younger (vmcnt retires in order) and stay in flight, output stores in between only make the wait stricter --;
     // behind the barrier that holds for every wave, and every wave has consumed stage jr - 2, whose buffer the next
@@ -909,9 +913,10 @@ __global__ __launch_bounds__(256, 1) void td_frag_gemm_res_kernel(TdFragGemmPara
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (jr + LEAD < nst) stage_dma(jr + LEAD);
-        rbase = sm + (size_t)(jr % NSTG) * KH * TD_FRAG_BYTES + lane * 16;
+        rbase = sm + ((size_t)(jr % NSTG) * KH + kh_half * KHL) * TD_FRAG_BYTES + lane * 16;
         ++jr;
     };
+    float *red = (float *)(sm + (size_t)NSTG * KH * TD_FRAG_BYTES) + ((wave / KS) * 64 + lane) * 16;   // KS = 2: the pair's hand-over
     bf16x8 bq[RING];
     enter();
 #pragma unroll
@@ -928,12 +933,27 @@ __global__ __launch_bounds__(256, 1) void td_frag_gemm_res_kernel(TdFragGemmPara
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], bq[i % RING], acc, 0, 0, 0);
             constexpr int r = (i + RING) % NK;          // fragment read now: of this tile, or of the next one
             if (i + RING < NK || more) {
-                if constexpr (r % KH == 0) enter();
-                bq[i % RING] = *(const bf16x8 *)(rbase + (r % KH) * TD_FRAG_BYTES);
+                if constexpr (r % KHL == 0) enter();
+                bq[i % RING] = *(const bf16x8 *)(rbase + (r % KHL) * TD_FRAG_BYTES);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (rb0 < p.nrb) {
+        if constexpr (KS == 2) {
+            // (the next write of `red` lies a whole tile, i.e. NT stage barriers, behind this read)
+            if (kh_half == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) *(f32x4 *)(red + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+            }
+            __syncthreads();
+            if (kh_half == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const f32x4 o = *(const f32x4 *)(red + r);
+                    acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+                }
+            }
+        }
+        if (rb0 < p.nrb && kh_half == 0) {
             bf16x8 a, b;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a[j] = (__bf16)acc[j]; b[j] = (__bf16)acc[8 + j]; }
@@ -944,25 +964,30 @@ __global__ __launch_bounds__(256, 1) void td_frag_gemm_res_kernel(TdFragGemmPara
     }
 }
 
-template <int NT, int KH>
+template <int NT, int KH, int KS, int NSTG>
 static int td_launch_frag_gemm_res(const TdFragGemmParams &q, hipStream_t stream) {
-    const int rbg = td_cdiv(q.nrb, 4);
+    const int rbg = td_cdiv(q.nrb, 4 / KS);
     // enough chunks of tiles to give every CU a workgroup, at least four tiles each (the weights are loaded per workgroup)
     int chunks = td_cdiv(TDC_CUS, rbg);
+    if (chunks < 1) chunks = 1;
     if (chunks > td_cdiv(q.ntiles, 4)) chunks = td_cdiv(q.ntiles, 4);
     const int per = td_cdiv(q.ntiles, chunks);
     chunks = td_cdiv(q.ntiles, per);
-    const size_t shm = (size_t)TD_FG_STAGES * KH * TD_FRAG_BYTES;
-    TD_HIP(hipFuncSetAttribute((const void *)td_frag_gemm_res_kernel<NT, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((td_frag_gemm_res_kernel<NT, KH>), dim3(rbg * 8 * td_cdiv(chunks, 8)), dim3(256), shm, stream, q, per);
+    const size_t shm = (size_t)NSTG * KH * TD_FRAG_BYTES + (KS == 2 ? 2 * 64 * 16 * sizeof(float) : 0);
+    TD_HIP(hipFuncSetAttribute((const void *)td_frag_gemm_res_kernel<NT, KH, KS, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((td_frag_gemm_res_kernel<NT, KH, KS, NSTG>), dim3(rbg * 8 * td_cdiv(chunks, 8)), dim3(256), shm, stream, q, per);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
 
 static int td_frag_gemm(const TdFragGemmParams &q, hipStream_t stream) {
     if (q.in_frags == 4 * q.kh && q.kh == 16) {
-        if (q.nterm == 4) return td_launch_frag_gemm_res<4, 16>(q, stream);
-        if (q.nterm == 3) return td_launch_frag_gemm_res<3, 16>(q, stream);
+        if (q.nterm == 4) return td_launch_frag_gemm_res<4, 16, 1, TD_FG_STAGES>(q, stream);
+        if (q.nterm == 3) return td_launch_frag_gemm_res<3, 16, 1, TD_FG_STAGES>(q, stream);
+    }
+    if (q.in_frags == 4 * q.kh && q.kh == 32) {     // hidden in (480, 512]: two waves per row block, four stages of 32 KiB
+        if (q.nterm == 4) return td_launch_frag_gemm_res<4, 32, 2, 4>(q, stream);
+        if (q.nterm == 3) return td_launch_frag_gemm_res<3, 32, 2, 4>(q, stream);
     }
     hipLaunchKernelGGL(td_frag_gemm_kernel, dim3(td_cdiv(q.nrb, 4), q.ntiles), dim3(256), 0, stream, q);
     TD_LAUNCH_CHECK();
