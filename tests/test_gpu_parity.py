@@ -152,13 +152,18 @@ def test_sample_chain_external_noise(name, use_graph, dev):
     want = od.decode(z, idx, g["num_idx"], g["cat_idx"], channels=c_io)
     assert out.shape == g["sample"].shape
     cat = list(g["cat_idx"])
-    mism = (out[:, cat] != want[:, cat]).mean()
-    assert mism < 0.03, mism
+    # Bounds chosen from tools/chain_margins.py on MI355X: 0 flipped cells and
+    # 4.8e-4 .. 8.4e-4 against the bf16 oracle, 0 cells and 3.3e-3 .. 1.05e-2
+    # against the reference's fp32 chain (the chains free-run, so a rounding
+    # difference in one step feeds the next; the per-step gate is
+    # test_chain_teacher_forced_margin_gate).
+    flips = int((out[:, cat] != want[:, cat]).sum())
+    assert flips <= 1, flips
     num = list(g["num_idx"])
-    assert np.abs(out[:, num] - want[:, num]).max() < 3e-2
+    assert np.abs(out[:, num] - want[:, num]).max() < 4e-3
     # against the reference's fp32 chain: same statistics within the bf16 tolerance
-    assert (out[:, cat] != g["sample"][:, cat]).mean() < 0.06
-    assert np.abs(out[:, num] - g["sample"][:, num]).max() < 8e-2
+    assert (out[:, cat] != g["sample"][:, cat]).mean() < 0.03
+    assert np.abs(out[:, num] - g["sample"][:, num]).max() < 3e-2
 
 
 def test_gaussian_chain(dev):
