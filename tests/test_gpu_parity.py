@@ -126,7 +126,9 @@ def test_reverse_steps(name, dev):
         margin = od.gumbel_margin(g[p + "log_theta"], g[p + "uniforms"])
         safe = margin > (1e-3 if i <= 10 else 1e-5)
         assert np.array_equal(idx.cpu().numpy()[safe], g[p + "idx_new"][safe])
-        # and bit-exact against the oracle given identical inputs
+        # and against the oracle given identical inputs: equal except Gumbel near-ties
+        # (both score in f32, with libm's logf/expf on the host and the device's on the GPU;
+        # every cell above the margin is checked exactly, just above)
         _, idx_o = od.reverse_step(g[p + "model_out"], g[p + "z"], g[p + "idx"], int(i), g[p + "noise"], g[p + "uniforms"])
         assert (idx.cpu().numpy() != idx_o).mean() < 2e-3
 
