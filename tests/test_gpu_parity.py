@@ -126,11 +126,14 @@ def test_reverse_steps(name, dev):
         margin = od.gumbel_margin(g[p + "log_theta"], g[p + "uniforms"])
         safe = margin > (1e-3 if i <= 10 else 1e-5)
         assert np.array_equal(idx.cpu().numpy()[safe], g[p + "idx_new"][safe])
-        # and against the oracle given identical inputs: equal except Gumbel near-ties
-        # (both score in f32, with libm's logf/expf on the host and the device's on the GPU;
-        # every cell above the margin is checked exactly, just above)
-        _, idx_o = od.reverse_step(g[p + "model_out"], g[p + "z"], g[p + "idx"], int(i), g[p + "noise"], g[p + "uniforms"])
-        assert (idx.cpu().numpy() != idx_o).mean() < 2e-3
+        # and against the oracle given identical inputs: exactly equal wherever the oracle's own
+        # top-2 Gumbel gap exceeds the margin (both score in f32, libm's logf/expf on the host,
+        # the device's on the GPU, so a near-tie may resolve either way); near-ties stay rare
+        _, idx_o, det = od.reverse_step(g[p + "model_out"], g[p + "z"], g[p + "idx"], int(i), g[p + "noise"],
+                                        g[p + "uniforms"], details=True)
+        safe_o = od.gumbel_margin(det["log_theta"], g[p + "uniforms"]) > (1e-3 if i <= 10 else 1e-5)
+        assert np.array_equal(idx.cpu().numpy()[safe_o], idx_o[safe_o])
+        assert (~safe_o).mean() < 1e-2 and (idx.cpu().numpy() != idx_o).mean() < 2e-3
 
 
 @pytest.mark.parametrize("name", ["eicu_lstm_T8", "k3mix_gru_T6", "hirid_lstm_uni_T5"])
