@@ -200,17 +200,24 @@ def main():
     ap.add_argument("--train-batch", type=int, default=32, help="training probe: batch per micro-batch (reference default 32)")
     ap.add_argument("--train-steps", type=int, default=100, help="timed optimizer steps of the small-batch training probes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-oracle baseline sample")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one rank per GPU; what the driver runs); gloo only "
+                    "rehearses the multi-rank control flow with ranks sharing a GPU -- its numbers mean nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.backend != "nccl":       # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from timediff_amd import _lib
     from timediff_amd.ops import DenoiserKernels, DiffusionKernels, SamplerKernels
@@ -245,7 +252,7 @@ def main():
         """The same number on every rank (max over ranks): all ranks take the same stop decision."""
         if world == 1:
             return x
-        tt = torch.tensor([x], device=dev, dtype=torch.float64)
+        tt = torch.tensor([x], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
