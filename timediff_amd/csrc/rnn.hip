@@ -13,7 +13,7 @@ int td_head_fusion_mode(void);    // api.cpp
 // rnn_cluster.hip
 size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L);
-int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, const float *const *w, char *dst, hipStream_t stream);
+int td_cluster_pack_all(const td_rnn_config *cfg, const TdRnnGeom &g, const float *const *lw, char *packed, hipStream_t stream);
 int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayerParams &lp, const char *wcluster, size_t dir_stride,
                             bool layer0, unsigned long long *xch, hipStream_t stream);
 
@@ -120,7 +120,15 @@ struct TdPackParams {
     int H, In, nu, ng, kh, kx, fu, nf, ns, layer0, gru;
 };
 
-__global__ void td_pack_weights_kernel(TdPackParams p) {
+// One launch packs every (layer, direction) of a call: blockIdx.y selects the job (22 launches of ~5 us per optimizer
+// step were 1.5 % of the reference-batch training step).
+#define TD_PACK_JOBS 12
+struct TdPackJobs {
+    TdPackParams job[TD_PACK_JOBS];
+};
+
+__global__ void td_pack_weights_kernel(TdPackJobs jobs) {
+    const TdPackParams &p = jobs.job[blockIdx.y];
     const size_t total = (size_t)p.ns * TD_STAGE_FRAGS * 512;
     __bf16 *dst = (__bf16 *)p.dst;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -186,27 +194,32 @@ extern "C" int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const 
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
     TD_REQUIRE(lw && packed, "NULL argument");
+    for (int i = 0; i < cfg->layers * cfg->dirs * 4; ++i)
+        TD_REQUIRE(lw[i], "NULL weight pointer for layer %d dir %d", i / 4 / cfg->dirs, i / 4 % cfg->dirs);
+    TdPackJobs jobs;
+    int nj = 0, blocks = 1;
+    auto flush = [&]() {
+        if (nj) hipLaunchKernelGGL(td_pack_weights_kernel, dim3(blocks, nj), dim3(256), 0, (hipStream_t)stream, jobs);
+        nj = 0; blocks = 1;
+    };
     for (int l = 0; l < cfg->layers; ++l)
         for (int d = 0; d < cfg->dirs; ++d) {
             const TdLayerGeom &lg = l == 0 ? g.g0 : g.g1;
             const float *const *w = lw + (size_t)(l * cfg->dirs + d) * 4;
-            TD_REQUIRE(w[0] && w[1] && w[2] && w[3], "NULL weight pointer for layer %d dir %d", l, d);
-            TdPackParams p;
+            TdPackParams &p = jobs.job[nj++];
             p.w_ih = w[0]; p.w_hh = w[1]; p.b_ih = w[2]; p.b_hh = w[3];
             p.dst = (char *)packed + g.layer_off[l] + (size_t)d * lg.dir_bytes;
             p.H = cfg->hidden; p.In = l == 0 ? cfg->c_in : cfg->dirs * cfg->hidden;
             p.nu = lg.nu; p.ng = lg.ng; p.kh = lg.kh; p.kx = lg.kx; p.fu = lg.fu; p.nf = lg.nf; p.ns = lg.ns;
             p.layer0 = l == 0; p.gru = cfg->gru;
-            size_t total = (size_t)lg.ns * TD_STAGE_FRAGS * 512;
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(td_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-            TD_LAUNCH_CHECK();
-            if (g.nu == TD_CLUSTER_NU) {
-                rc = td_cluster_pack(cfg, g, l, w, (char *)packed + g.cl_off[l] + (size_t)d * g.cl_dir[l == 0 ? 0 : 1], (hipStream_t)stream);
-                if (rc != TD_OK) return rc;
-            }
+            const size_t total = (size_t)lg.ns * TD_STAGE_FRAGS * 512;
+            const int b = (int)((total + 255) / 256);
+            blocks = b > blocks ? (b > 4096 ? 4096 : b) : blocks;
+            if (nj == TD_PACK_JOBS) { flush(); TD_LAUNCH_CHECK(); }
         }
+    flush();
+    TD_LAUNCH_CHECK();
+    if (g.nu == TD_CLUSTER_NU) return td_cluster_pack_all(cfg, g, lw, (char *)packed, (hipStream_t)stream);
     return TD_OK;
 }
 

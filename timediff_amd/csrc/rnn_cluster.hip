@@ -43,7 +43,13 @@ __device__ __forceinline__ float tdc_scale(int gru, int slot) {
     return tanh_gate ? TD_GATE_SCALE_TANH : TD_GATE_SCALE_SIGMOID;
 }
 
-__global__ void td_cluster_pack_kernel(TdClusterPack p) {
+#define TDC_PACK_JOBS 12
+struct TdClusterPackJobs {
+    TdClusterPack job[TDC_PACK_JOBS];
+};
+
+__global__ void td_cluster_pack_kernel(TdClusterPackJobs jobs) {   // blockIdx.y: (layer, direction) of the call
+    const TdClusterPack &p = jobs.job[blockIdx.y];
     const size_t slice = tdc_slice_bytes(p.nfr);
     const size_t per_slice = 1024 + (size_t)p.nfr * 512;   // elements: 1024 fp32 bias + nfr * 512 bf16
     const size_t total = (size_t)p.nu * TDC_WAVES * per_slice;
@@ -582,14 +588,24 @@ bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
     return g.nu == 8 && L >= 4 && L < 4096 && nbb >= 1;
 }
 
-int td_cluster_pack(const td_rnn_config *cfg, const TdRnnGeom &g, int layer, const float *const *w, char *dst, hipStream_t stream) {
-    TdClusterPack p;
-    p.w_ih = w[0]; p.w_hh = w[1]; p.b_ih = w[2]; p.b_hh = w[3];
-    p.dst = dst; p.H = cfg->hidden; p.In = layer == 0 ? cfg->c_in : cfg->dirs * cfg->hidden;
-    p.nu = g.nu; p.kh = g.kh; p.layer0 = layer == 0; p.kx0 = g.kx0; p.dirs_in = g.dirs; p.gru = cfg->gru;
-    p.nfr = g.kh + (layer == 0 ? 2 * g.kx0 : g.dirs * g.kh);
-    hipLaunchKernelGGL(td_cluster_pack_kernel, dim3(1024), dim3(256), 0, stream, p);
-    TD_LAUNCH_CHECK();
+int td_cluster_pack_all(const td_rnn_config *cfg, const TdRnnGeom &g, const float *const *lw, char *packed, hipStream_t stream) {
+    TdClusterPackJobs jobs;
+    int nj = 0;
+    for (int l = 0; l < cfg->layers; ++l)
+        for (int d = 0; d < cfg->dirs; ++d) {
+            const float *const *w = lw + (size_t)(l * cfg->dirs + d) * 4;
+            TdClusterPack &p = jobs.job[nj++];
+            p.w_ih = w[0]; p.w_hh = w[1]; p.b_ih = w[2]; p.b_hh = w[3];
+            p.dst = packed + g.cl_off[l] + (size_t)d * g.cl_dir[l == 0 ? 0 : 1];
+            p.H = cfg->hidden; p.In = l == 0 ? cfg->c_in : cfg->dirs * cfg->hidden;
+            p.nu = g.nu; p.kh = g.kh; p.layer0 = l == 0; p.kx0 = g.kx0; p.dirs_in = g.dirs; p.gru = cfg->gru;
+            p.nfr = g.kh + (l == 0 ? 2 * g.kx0 : g.dirs * g.kh);
+            if (nj == TDC_PACK_JOBS || (l == cfg->layers - 1 && d == cfg->dirs - 1)) {
+                hipLaunchKernelGGL(td_cluster_pack_kernel, dim3(1024, nj), dim3(256), 0, stream, jobs);
+                TD_LAUNCH_CHECK();
+                nj = 0;
+            }
+        }
     return TD_OK;
 }
 

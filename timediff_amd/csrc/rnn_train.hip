@@ -282,7 +282,13 @@ struct TdPackTParams {
     int gate[4];
 };
 
-__global__ __launch_bounds__(256) void td_pack_weights_T_kernel(TdPackTParams p) {
+#define TD_PACKT_JOBS 12
+struct TdPackTJobs {
+    TdPackTParams job[TD_PACKT_JOBS];
+};
+
+__global__ __launch_bounds__(256) void td_pack_weights_T_kernel(TdPackTJobs jobs) {   // blockIdx.y: the job
+    const TdPackTParams &p = jobs.job[blockIdx.y];
     const size_t total = (size_t)p.nrb * p.nterm * p.kh * 512;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int j = (int)(i % 8), lane = (int)((i / 8) % 64);
@@ -334,20 +340,30 @@ extern "C" int td_rnn_pack_weights_T(const td_rnn_config *cfg, const float *cons
     if (rc != TD_OK) return rc;
     TD_REQUIRE(lw && packT, "NULL argument");
     const TdPackTGeom t = td_packT_geom(cfg, g);
+    TdPackTJobs jobs;
+    int nj = 0;
+    auto push = [&](const TdPackTParams &p, bool last) {
+        jobs.job[nj++] = p;
+        if (nj == TD_PACKT_JOBS || last) {
+            hipLaunchKernelGGL(td_pack_weights_T_kernel, dim3(1024, nj), dim3(256), 0, (hipStream_t)stream, jobs);
+            nj = 0;
+        }
+    };
     for (int l = 0; l < cfg->layers; ++l)
         for (int d = 0; d < cfg->dirs; ++d) {
             const float *const *w = lw + (size_t)(l * cfg->dirs + d) * 4;
             char *base = (char *)packT + t.layer_off[l] + (size_t)d * (t.hh_bytes + (l > 0 ? t.ih_bytes : 0));
+            const bool last = l == cfg->layers - 1 && d == cfg->dirs - 1;
             TdPackTParams p;
             p.H = cfg->hidden; p.kh = g.kh; p.nterm = t.ng; p.nu = g.nu;
             for (int i = 0; i < 4; ++i) p.gate[i] = i;
             // W_hh^T: rows of the result = own hidden units
             p.w = w[1]; p.ld = cfg->hidden; p.dst = (__bf16 *)base; p.nrb = g.nu; p.hh = 1;
-            hipLaunchKernelGGL(td_pack_weights_T_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, p);
+            push(p, last && l == 0);
             TD_LAUNCH_CHECK();
             if (l > 0) {
                 p.w = w[0]; p.ld = cfg->dirs * cfg->hidden; p.dst = (__bf16 *)(base + t.hh_bytes); p.nrb = g.dirs * g.nu; p.hh = 0;
-                hipLaunchKernelGGL(td_pack_weights_T_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, p);
+                push(p, last);
                 TD_LAUNCH_CHECK();
             }
         }
