@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void td_pack_input_kernel(const float *__restr
 __global__ __launch_bounds__(256) void td_state_to_frags_kernel(td_diffusion_config c, int sumk, const float *__restrict__ z,
                                                                 const uint8_t *__restrict__ idx, char *__restrict__ dst, int B,
                                                                 int nbb, int kx0) {
-    __shared__ float tile[32 * 32 * (TD_SF_LT + 1)];   // [16 kx0 <= 32][32][TD_SF_LT + 1] (static: c_in <= 32)
+    extern __shared__ float tile[];   // [16 kx0][32][TD_SF_LT + 1]: 34 KiB at c_in <= 16, four workgroups per CU
     const int L = c.seq_len, CP = 16 * kx0, C_io = c.n_num + sumk;
     const int l0 = blockIdx.x * TD_SF_LT, bblk = blockIdx.y, tid = threadIdx.x;
     const int RS = TD_SF_LT + 1;
@@ -1016,8 +1016,11 @@ int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *co
         int sumk = 0;
         for (int v = 0; v < dcfg->n_cat; ++v) sumk += dcfg->num_classes[v];
         TD_REQUIRE(dcfg->n_num + sumk == cfg->c_in && dcfg->seq_len == L, "diffusion state does not match the denoiser input");
-        hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), 0, stream, *dcfg, sumk, z, idx, x0,
-                           batch, nbb, g.kx0);
+        const size_t sf_shm = (size_t)16 * g.kx0 * 32 * (TD_SF_LT + 1) * sizeof(float);
+        if (sf_shm > 65536)
+            TD_HIP(hipFuncSetAttribute((const void *)td_state_to_frags_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_shm));
+        hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), sf_shm, stream, *dcfg, sumk, z, idx,
+                           x0, batch, nbb, g.kx0);
         TD_LAUNCH_CHECK();
     }
     char *acts[16];
