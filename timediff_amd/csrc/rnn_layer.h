@@ -75,6 +75,14 @@ __device__ __forceinline__ float td_unpark(float a) {
 }
 
 
+// A/B switch (TdSched::CARRY): 1 = the gate math of a step's last block rides in the next step's block 0 instead of running
+// in the open behind its own step.  Measured at the bench shape: correct (the whole GPU suite passes)
+// and 1 % SLOWER -- the kernel runs at the chip's power limit, where hiding VALU work under the MFMAs lowers the clock by
+// what the overlap would have saved.  Off.
+#ifndef TD_CARRY_TAIL
+#define TD_CARRY_TAIL 0
+#endif
+
 #define TD_RING_FRAGS 8   // weight fragments per ring stage
 #define TD_RING_DEPTH 4   // ring stages
 #define TD_RING_BYTES (TD_RING_FRAGS * TD_FRAG_BYTES)
@@ -116,6 +124,13 @@ struct TdSched {
     // ring holds 8 = one stage of fragments), so no wave needs to drain its LDS reads at the boundary.
     static constexpr int LEAD = TD_RING_DEPTH - 2;
     static constexpr int PIECE_STEP = 2;  // pieces go out at positions 1, 3
+    // CARRY: the gate math of a step's LAST block has no later block of that step to hide behind (192 micro-ops = 1.4 us
+    // per step in the open: 6 % of the first layer, 3 % of an upper one).  The next step's block 0 takes it: its bias
+    // slots and its recurrent slots for k-steps 0 .. KH - 3 read nothing the last block produces (h of the last block's
+    // units is k-steps KH - 2, KH - 1), and with NU even block 0 accumulates into the other accumulator set.  Step 0
+    // carries the gates of an all-zero accumulator set over a zero state, which is exactly the initial state again.
+    static constexpr bool CARRY = TD_CARRY_TAIL && !SAVE && !HEAD && NU % 2 == 0;
+    static constexpr int CARRY_SLOTS = 4 + (KH - 2) * NG;
     static_assert(T::APD <= TD_RING_FRAGS, "the LDS read ring must not reach back two stages");
 
     // weight fragment whose LDS read is issued in slot F (-1: none)
@@ -150,7 +165,7 @@ struct TdSched {
     static constexpr bool boundary(int F) { return refill_of(F) >= 0 && refill_of(F) % TD_RING_FRAGS == 0; }
     // room for gate-math micro-ops beside slot F's MFMA (block 0 of a step has no previous block to finish)
     static constexpr int capacity(int F) {
-        if (F / FU == 0) return 0;
+        if (F / FU == 0 && (!CARRY || F >= CARRY_SLOTS)) return 0;
         // head slots: the last four multiply the last block's own h_t, i.e. follow every one of its gate micro-ops
         if (F >= NFB && F - NFB >= HF - 4) return 0;
         if (boundary(F)) return 0;  // wait + barrier
@@ -288,6 +303,15 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) hold[ks] = zero;
     }
+    // CARRY: where the carried block's h goes.  Step 0 carries nothing real: its two stores (they are part of the counted
+    // vector-memory stream) write zeros to the row this wave writes last, long before that row's own store.
+    char *opc = p.out + (((size_t)(dir ? 0 : p.L - 1) * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES + lane * 16;
+    if constexpr (S::CARRY) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[(NU - 1) & 1][g][r] = 0.f;
+    }
 
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
@@ -341,8 +365,10 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         // micro-op q of block ub's gate nonlinearities; rows go in pairs so that the dependent exp -> rcp -> fma
         // chain of one row is separated by the other row's instructions.
         // row r of the accumulator = unit 32u + (r&3) + 8(r>>2) + 4hf
-        auto gate_op = [&](auto ubc, auto qc) {
+        auto gate_op = [&](auto ubc, auto qc, auto carried) {
             constexpr int ub = decltype(ubc)::value, q = decltype(qc)::value;
+            constexpr bool CARRIED = decltype(carried)::value;   // the previous step's last block, finished inside this step's block 0
+            auto &hdst = [&]() -> bf16x8(&)[KH] { if constexpr (CARRIED) return hold; else return hn; }();
             constexpr int pair = q / (2 * NOPS), w = q % (2 * NOPS), o = w / 2, r = 2 * pair + (w & 1);
             constexpr float P2L2E = TD_GATE_SCALE_TANH;
             f32x16(&a)[4] = acc[ub & 1];
@@ -406,8 +432,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 if constexpr ((r & 1) == 0) hprev = hval;
                 else {
                     const __bf16 b0 = (__bf16)hprev, b1 = (__bf16)hval;
-                    hn[2 * ub + (r >> 3)][(r & 7) - 1] = b0;
-                    hn[2 * ub + (r >> 3)][r & 7] = b1;
+                    hdst[2 * ub + (r >> 3)][(r & 7) - 1] = b0;
+                    hdst[2 * ub + (r >> 3)][r & 7] = b1;
                     if constexpr (HEAD) {
                         const float f0 = (float)b0, f1 = (float)b1;
                         hs1 += f0 + f1;
@@ -418,8 +444,9 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             if constexpr (q == NQ - 1 && !HEAD) {
                 // h_t of this block goes to HBM for the next layer right away (streaming store: it must not push
                 // the weights out of this XCD's L2)
-                __builtin_nontemporal_store(hn[2 * ub], (bf16x8 *)(op + (2 * ub) * TD_FRAG_BYTES));
-                __builtin_nontemporal_store(hn[2 * ub + 1], (bf16x8 *)(op + (2 * ub + 1) * TD_FRAG_BYTES));
+                char *o = CARRIED ? opc : op;
+                __builtin_nontemporal_store(hdst[2 * ub], (bf16x8 *)(o + (2 * ub) * TD_FRAG_BYTES));
+                __builtin_nontemporal_store(hdst[2 * ub + 1], (bf16x8 *)(o + (2 * ub + 1) * TD_FRAG_BYTES));
             }
         };
 
@@ -482,7 +509,14 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
                     td_static_for<q1 - q0>([&](auto jc) {
                         gate_op(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{},
-                                std::integral_constant<int, q0 + decltype(jc)::value>{});
+                                std::integral_constant<int, q0 + decltype(jc)::value>{}, std::false_type{});
+                    });
+                } else if constexpr (S::CARRY) {
+                    // the previous step's last block (step 0: zeros over zeros)
+                    constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
+                    td_static_for<q1 - q0>([&](auto jc) {
+                        gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{},
+                                std::true_type{});
                     });
                 }
                 // pin the slot: left alone, the scheduler sinks every ds_read next to its MFMA and piles the
@@ -491,15 +525,19 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             });
         });
 
-        if constexpr (!HEAD) {
+        if constexpr (S::CARRY) {
+            // the last block's gates ride in the next step's block 0; only the last step finishes them here
+            opc = op;
+            if (last_step) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc, std::true_type{}); });
+        } else if constexpr (!HEAD) {
             // the last block's gates have no MFMAs left to hide behind
-            td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
+            td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc, std::false_type{}); });
         } else {
             // head slots: partial projection of h_t, k-step by k-step (hi and lo part of the folded weights); the k-steps of
             // the blocks before the last run beside the last block's gate math, the last block's own four slots after it
             f32x16 &hacc = acc[NU & 1][0];     // the accumulator set the last block does not use
             // a single unit block: every head slot multiplies that block's own h_t, its gate math has nothing to hide behind
-            if constexpr (HF <= 4) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
+            if constexpr (HF <= 4) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc, std::false_type{}); });
             td_static_for<HF>([&](auto fc) {
                 constexpr int f = decltype(fc)::value;
                 constexpr int F = NFB + f;
@@ -513,7 +551,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     A[F % APD] = refill(std::integral_constant<int, (S::refill_of(F) >= 0 ? S::refill_of(F) : 0)>{});
                 constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
                 td_static_for<q1 - q0>([&](auto jc) {
-                    gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{});
+                    gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{},
+                            std::false_type{});
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -530,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 
         // h_t replaces h_{t-1} only now: every unit block above consumed the old one
 #pragma unroll
-        for (int ks = 0; ks < KH; ++ks) hold[ks] = hn[ks];
+        for (int ks = 0; ks < (S::CARRY ? KH - 2 : KH); ++ks) hold[ks] = hn[ks];
     }
     // no LDS-DMA piece may still be in flight when the workgroup's LDS is handed on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
