@@ -77,8 +77,8 @@ __device__ __forceinline__ float td_unpark(float a) {
 
 // A/B switch (TdSched::CARRY): 1 = the gate math of a step's last block rides in the next step's block 0 instead of running
 // in the open behind its own step.  Measured at the bench shape: correct (the whole GPU suite passes)
-// and 1 % SLOWER -- the kernel runs at the chip's power limit, where hiding VALU work under the MFMAs lowers the clock by
-// what the overlap would have saved.  Off.
+// and 1 % SLOWER -- consistent with a kernel at the chip's power limit, where hiding VALU work under the MFMAs lowers the
+// clock by what the overlap would have saved.  Off.
 #ifndef TD_CARRY_TAIL
 #define TD_CARRY_TAIL 0
 #endif
