@@ -77,8 +77,9 @@ __device__ __forceinline__ float td_unpark(float a) {
 
 // A/B switch (TdSched::CARRY): 1 = the gate math of a step's last block rides in the next step's block 0 instead of running
 // in the open behind its own step.  Measured at the bench shape: correct (the whole GPU suite passes)
-// and 1 % SLOWER -- consistent with a kernel at the chip's power limit, where hiding VALU work under the MFMAs lowers the
-// clock by what the overlap would have saved.  Off.
+// and 1 % SLOWER: 54.5 instead of 52.6 cycles per MFMA at an unchanged clock -- block 0 has only 60 slots that do not read the
+// last block's h, and 3 to 5 dependent micro-ops in front of each of their MFMAs stall the in-order issue.  Off until the
+// stream order gives block 0 enough independent slots (input k-steps before the last two recurrent ones).
 #ifndef TD_CARRY_TAIL
 #define TD_CARRY_TAIL 0
 #endif
