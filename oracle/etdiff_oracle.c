@@ -347,11 +347,11 @@ EXPORT void or_rnn_forward(const OrRnnCfg *c, const float *const *lw, const floa
 /* Backward of the denoiser (autograd of blocks.py:333-341), fp32.  grads use the same index
  * scheme as the weights (glw / gmisc), must be zero-initialised by the caller and are
  * accumulated over the batch.  gx: (B, C_in, L) or NULL. */
-EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const float *const *misc, const float *x,
-                            const int64_t *t, int B, int L, const float *gy, float *const *glw, float *const *gmisc,
-                            float *gx, float *y_out) {
+static void rnn_backward_range(const OrRnnCfg *c, const float *const *lw, const float *const *misc, const float *x,
+                               const int64_t *t, int b0, int b1, int L, const float *gy, float *const *glw,
+                               float *const *gmisc, float *gx, float *y_out) {
     const int H = c->H, D = c->D, DH = D * H, G = c->gru ? 3 : 4, AW = c->gru ? 4 * H : 5 * H;
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < b1; ++b) {
         SeqSave sv;
         sv.layer_out = (float **)malloc(sizeof(float *) * (c->N + 1));
         sv.act = (float **)malloc(sizeof(float *) * c->N * D);
@@ -526,6 +526,51 @@ EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const flo
         free(sv.layer_in); free(sv.layer_out); free(sv.act); free(sv.xhat); free(sv.rstd); free(sv.temb); free(sv.h1pre); free(sv.h1);
         free(sv.sinus); free(sv.film); free(y);
     }
+}
+
+/* The batch is cut into a FIXED number of chunks (independent of the thread count), each chunk accumulates into
+ * gradient buffers of its own and the chunks are added up in order: the result does not depend on how many threads
+ * ran.  (Test infrastructure: the L = 272 parity tests would otherwise wait minutes for a serial sweep.) */
+#define OR_BWD_CHUNKS 16
+EXPORT void or_rnn_backward(const OrRnnCfg *c, const float *const *lw, const float *const *misc, const float *x,
+                            const int64_t *t, int B, int L, const float *gy, float *const *glw, float *const *gmisc,
+                            float *gx, float *y_out) {
+    const int H = c->H, D = c->D, DH = D * H, G = c->gru ? 3 : 4, TD = c->time_dim, ED = c->embed_dim;
+    const int nch = B < OR_BWD_CHUNKS ? B : OR_BWD_CHUNKS;
+    if (nch <= 1) {
+        rnn_backward_range(c, lw, misc, x, t, 0, B, L, gy, glw, gmisc, gx, y_out);
+        return;
+    }
+    const int nlw = c->N * D * 4;
+    size_t lsz[nlw], msz[M_COUNT];
+    for (int l = 0; l < c->N; ++l)
+        for (int d = 0; d < D; ++d) {
+            const int In = l == 0 ? c->C_in : DH;
+            size_t *z = lsz + (size_t)(l * D + d) * 4;
+            z[0] = (size_t)G * H * In; z[1] = (size_t)G * H * H; z[2] = z[3] = (size_t)G * H;
+        }
+    msz[M_TE_W1] = (size_t)TD * ED; msz[M_TE_B1] = TD; msz[M_TE_W2] = (size_t)TD * TD; msz[M_TE_B2] = TD;
+    msz[M_FILM_W] = (size_t)2 * DH * TD; msz[M_FILM_B] = 2 * DH; msz[M_LN_W] = DH; msz[M_LN_B] = DH;
+    msz[M_FC_W] = (size_t)c->C_out * DH; msz[M_FC_B] = c->C_out;
+    size_t total = 0;
+    for (int i = 0; i < nlw; ++i) total += lsz[i];
+    for (int i = 0; i < M_COUNT; ++i) total += msz[i];
+    float *pool = (float *)calloc(total * nch, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ch = 0; ch < nch; ++ch) {
+        float *pl[nlw], *pm[M_COUNT];
+        float *q = pool + total * ch;
+        for (int i = 0; i < nlw; ++i) { pl[i] = q; q += lsz[i]; }
+        for (int i = 0; i < M_COUNT; ++i) { pm[i] = q; q += msz[i]; }
+        const int b0 = (int)((long)B * ch / nch), b1 = (int)((long)B * (ch + 1) / nch);
+        rnn_backward_range(c, lw, misc, x, t, b0, b1, L, gy, pl, pm, gx, y_out);
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const float *q = pool + total * ch;
+        for (int i = 0; i < nlw; ++i) { for (size_t k = 0; k < lsz[i]; ++k) glw[i][k] += q[k]; q += lsz[i]; }
+        for (int i = 0; i < M_COUNT; ++i) { for (size_t k = 0; k < msz[i]; ++k) gmisc[i][k] += q[k]; q += msz[i]; }
+    }
+    free(pool);
 }
 
 /* ------------------------------------------------------------------------------------------ */
