@@ -96,12 +96,32 @@ def cpu_baseline(sd, cols, L, T, tables, seconds_target=15.0):
                        f"{per_step:.2f} s/step, extrapolated to T={T}")
 
 
-def parity_gates(dev, den, diff, sd, cols, L, T, tables, B=32):
-    """SURVEY.md 8(d) "parity gates reported next to perf", at the bench's own architecture and weights on a small
-    batch: the HIP path against the CPU oracle (the checker, as in tests/) at t in {T-1, T/2, 10, 0} -- denoiser output,
-    the reverse update's x0_hat / posterior mean / log theta, sampled class ids wherever the Gumbel-perturbed top-2
-    margin exceeds the tolerance, and the loss with its gradient."""
+def parity_gates(dev, den, diff, sampler, sd, cols, L, T, tables, bench_batch, B=32):
+    """SURVEY.md 8(d) "parity gates reported next to perf", at the bench's own architecture and weights: the HIP path
+    against the CPU oracle (the checker, as in tests/) at t in {T-1, T/2, 10, 0} -- denoiser output, the reverse update's
+    x0_hat / posterior mean / log theta, sampled class ids wherever the Gumbel-perturbed top-2 margin exceeds the
+    tolerance, and the loss with its gradient.  The denoiser runs the kernel family the timed chains run: the small batch
+    with the batch-block family forced (td_set_layer_kernel), and once more at the bench's own batch size under AUTO with
+    the head fused into the top layer as in the chain, the oracle on a subset of the sequences."""
     from oracle import oracle as orc
+    from timediff_amd import _lib
+    lib = _lib.lib()
+    names = {_lib.LAYER_KERNEL_BATCH: "batch-block (rnn_layer.h)", _lib.LAYER_KERNEL_UNITS: "unit-split (rnn_wide.hip)",
+             _lib.LAYER_KERNEL_CLUSTER: "cluster (rnn_cluster.hip)"}
+    timed_family = lib.td_rnn_layer_kernel_choice(C.byref(den.cfg), bench_batch, L)
+    _lib.check(lib.td_set_layer_kernel(timed_family))
+    try:
+        gates = _parity_gates_body(dev, den, diff, sampler, sd, cols, L, T, tables, bench_batch, B, orc)
+    finally:
+        lib.td_set_layer_kernel(_lib.LAYER_KERNEL_AUTO)
+        lib.td_set_head_fusion(_lib.HEAD_FUSION_AUTO)
+    gates["kernel_family"] = names.get(timed_family, str(timed_family))
+    return gates
+
+
+def _parity_gates_body(dev, den, diff, sampler, sd, cols, L, T, tables, bench_batch, B, orc):
+    from timediff_amd import _lib
+    lib = _lib.lib()
     o16, o32 = orc.Denoiser({k: v.numpy() for k, v in sd.items()}, bf16=True), orc.Denoiser({k: v.numpy() for k, v in sd.items()})
     od = orc.Diffusion(len(cols["num"]), cols["K"], L, T, tables=tables)
     rng = np.random.default_rng(11)
@@ -142,7 +162,28 @@ def parity_gates(dev, den, diff, sd, cols, L, T, tables, B=32):
     gates["loss"] = dict(rel_err=float(abs(loss.item() - ref["loss"]) / abs(ref["loss"])),
                          grad_rel_err=float(np.abs(grad.cpu().numpy() - ref["grad"]).max() / np.abs(ref["grad"]).max()))
     gates["sample"] = f"{B} eICU-shaped sequences, L={L}, the bench's weights; tolerances as in tests/test_gpu_parity.py"
+    # the timed launch shape itself: bench_batch sequences under AUTO, one FiLM row, head inside the top layer's kernel
+    lib.td_set_layer_kernel(_lib.LAYER_KERNEL_AUTO)
+    _lib.check(lib.td_set_head_fusion(_lib.HEAD_FUSION_ON))
+    z, idx = diff.prior(bench_batch, seed=11)
+    x_in = diff.build_input(z, idx)
+    t = T - 1
+    mo = den.forward(x_in, film=sampler._film[t:t + 1])
+    rows = np.unique(np.concatenate([np.arange(0, 24), np.arange(0, bench_batch, max(bench_batch // 24, 1)),
+                                     np.arange(bench_batch - 16, bench_batch)]))
+    rows_t = torch.from_numpy(rows).to(dev)
+    want = o16.forward(x_in[rows_t].cpu().numpy(), np.full(len(rows), t, np.int64))
+    gates["timed_shape"] = dict(batch=bench_batch, head="fused into the top layer", rows_checked=int(len(rows)),
+                                model_out_vs_bf16_oracle=float(np.abs(mo[rows_t].cpu().numpy() - want).max()))
     return gates
+
+
+def _family_name(lib, et, seqs, L):
+    """Which recurrent-layer kernel family AUTO takes for a launch of `seqs` sequences of the trainer's denoiser."""
+    from timediff_amd import _lib
+    den = et.model.model._kernels or et.model.model.kernels()
+    fam = lib.td_rnn_layer_kernel_choice(C.byref(den.cfg), seqs, L)
+    return {_lib.LAYER_KERNEL_BATCH: "batch-block", _lib.LAYER_KERNEL_UNITS: "unit-split", _lib.LAYER_KERNEL_CLUSTER: "cluster"}.get(fam, str(fam))
 
 
 def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
@@ -155,13 +196,13 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
     from timediff_amd.data import TensorSeriesDataset
     torch.manual_seed(2023)
     width = len(cols["num"]) + sum(cols["K"])
-    C = len(cols["num"]) + len(cols["cat"])
+    n_ch = len(cols["num"]) + len(cols["cat"])
     rnn = RNN(input_channels=width, hidden_channels=H, output_channels=width, layers=N, model="lstm", bidirectional=True)
     diff = MixedDiffusion(rnn, seq_length=L, channels=width, numerical_features_indices=cols["num"],
                           categorical_features_indices=cols["cat"], categorical_num_classes=cols["K"], timesteps=T,
                           loss_lambda=0.8)
     g = torch.Generator().manual_seed(2023)
-    data = torch.rand(max(4 * batch, 256), C, L, generator=g)
+    data = torch.rand(max(4 * batch, 256), n_ch, L, generator=g)
     for c in cols["cat"]:
         data[:, c] = (data[:, c] > 0.5).float()
     et = ETDiff(diff, TensorSeriesDataset(data, cols["cat"]), train_batch_size=batch, gradient_accumulate_every=ga,
@@ -176,7 +217,34 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
     torch.cuda.synchronize()
     el = time.time() - t0
     assert torch.isfinite(loss).all()
-    return dict(value=steps / el, unit="optimizer steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
+    # roofline of the training half: the two kernels that carry the recurrent products of the layers above the first
+    # (saving forward, BPTT sweep), each bracketed by HIP events on its launch stream in a few extra untimed steps
+    from timediff_amd import _lib
+    lib = _lib.lib()
+    seqs = batch * ga if fuse else batch           # sequences per launch
+    D = 2
+    fwd_flops = seqs * D * 2.0 * L * 4 * H * (D * H + H)     # W_hh h + W_ih x, one layer, both directions
+    bptt_flops = seqs * D * 2.0 * L * 4 * H * H               # W_hh^T d a (d x and d W are separate GEMM launches)
+    kernels = {}
+    for kind, name, fl in ((_lib.PROFILE_LAYER_SAVE, "saving forward, layers above the first", fwd_flops),
+                           (_lib.PROFILE_BPTT_SWEEP, "BPTT sweep, layers above the first", bptt_flops)):
+        _lib.check(lib.td_profile_enable(kind))
+        for _ in range(3):
+            et.train_step()
+        cnt, ms = C.c_int32(0), C.c_float(0)
+        _lib.check(lib.td_profile_read(C.byref(cnt), C.byref(ms)))
+        _lib.check(lib.td_profile_enable(0))
+        avg_ms = ms.value / max(cnt.value, 1)
+        tf = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        kernels[name] = dict(family=_family_name(lib, et, seqs, L), launches_timed=cnt.value, avg_launch_ms=avg_ms,
+                             flops_per_launch=fl, achieved_tflops=tf, frac_of_mfma_peak=tf / MFMA_BF16_PEAK_TFLOPS)
+    width_ = len(cols["num"]) + sum(cols["K"])
+    step_flops = 3.0 * denoiser_flops_per_seq(width_, H, N, D, L) * batch * ga
+    roofline = dict(bound="mfma", peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", kernels=kernels,
+                    whole_step_tflops=step_flops / (el / steps) / 1e12,
+                    whole_step_frac=step_flops / (el / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    note="whole step = 3 x forward FLOPs x sequences / wall time per optimizer step")
+    return dict(value=steps / el, unit="optimizer steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup, roofline=roofline,
                 config=dict(workload=f"ETDiff eICU-shaped training step: global batch {batch}, grad-accum {ga}, L={L}, "
                                      f"3-layer bidirectional LSTM H={H}, T={T}, Adam + clip + EMA",
                             batch=batch, gradient_accumulate_every=ga,
@@ -295,13 +363,24 @@ def main():
     d2h_s = agree_max(time.time() - d0)
     del host
 
+    # every rank reports what it saw: the first SCALE run proves that N ranks, N devices and N disjoint patient ranges took part
+    mine = dict(rank=rank, local_rank=local_rank, world_size_env=world,
+                world_size_backend=(dist.get_world_size() if world > 1 else 1), backend=(dist.get_backend() if world > 1 else None),
+                device=torch.cuda.get_device_name(dev), device_index=torch.cuda.current_device(),
+                pci_bus_id=getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+                first_timed_chain_patients=[rank * B, (rank + 1) * B - 1], chains_timed=steps_done)
+    ranks_seen = [mine]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
+
     result = None
     if rank == 0:
         # roofline probe of the dominant kernel (recurrent layers above the first: td_rnn_layer_kernel<8,32,0,0>):
         # eager reverse steps with a HIP event pair around each launch on its own stream
         L_ = _lib.lib()
         z, idx = diff.prior(B, seed=7)
-        _lib.check(L_.td_profile_enable(1))
+        _lib.check(L_.td_profile_enable(_lib.PROFILE_LAYER_INFER))
         for s in range(args.probe_steps):
             t = T - 1 - s
             mo = den.forward(diff.build_input(z, idx), film=sampler._film[t:t + 1])
@@ -332,7 +411,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only: the other ranks would wait on it
             tabs = {k: v.numpy() for k, v in tables.items()}
             base = cpu_baseline(sd, cols, L, T, tabs, args.cpu_seconds)
-            base["parity"] = parity_gates(dev, den, diff, sd, cols, L, T, tabs)
+            base["parity"] = parity_gates(dev, den, diff, sampler, sd, cols, L, T, tabs, B)
         note("cpu baseline done" if base else "cpu baseline skipped")
         train = None
         if world == 1 and not args.no_train_probe:
@@ -354,7 +433,7 @@ def main():
                        "graph": True},
             "d2h_s_per_chain": d2h_s, "value_including_d2h": world * B * steps_done / (elapsed + steps_done * d2h_s),
             "denoiser_tflops_whole_chain": value * fl / 1e12,
-            "roofline": roofline, "cpu_baseline": base, "train": train,
+            "roofline": roofline, "cpu_baseline": base, "train": train, "ranks_seen": ranks_seen,
         }
     if world > 1:
         dist.barrier()

@@ -321,10 +321,19 @@ TD_API int td_set_dw_gemm(int32_t mode);
 enum { TD_HEAD_FUSION_AUTO = 0, TD_HEAD_FUSION_OFF = 1, TD_HEAD_FUSION_ON = 2 };
 TD_API int td_set_head_fusion(int32_t mode);
 
-/* Measurement aid, no counterpart in the reference: while enabled, every recurrent-layer kernel of the
- * widest kind (layers above the first) launched outside graph capture is bracketed by HIP events on
- * its own stream; td_profile_read waits for them and returns how many launches were timed and the sum
- * of their durations (ms), then resets. */
+/* No counterpart in the reference.  The cluster-persistent kernels (small batches at hidden 193..256) need every workgroup
+ * of a launch resident at once.  Where the device cannot give that (shared with another process, CU mask) a bounded poll
+ * inside the kernel times out: the outputs are poisoned with NaN and a word in device-writable host memory is raised.
+ * This call reads and clears that word without touching the GPU: TD_OK, or TD_ERR_HIP with a message.  Call it wherever
+ * the results of enqueued work have been waited for (the Python layer does, after it reads a loss or copies samples). */
+TD_API int td_check_async_errors(void);
+
+/* Measurement aid, no counterpart in the reference: while enabled, every launch of the selected kinds (a mask of
+ * TD_PROFILE_*: the recurrent-layer kernels of the layers above the first in their inference form, in their saving form,
+ * and the BPTT sweeps of those layers) made outside graph capture is bracketed by HIP events on its own stream;
+ * td_profile_read waits for them and returns how many launches were timed and the sum of their durations (ms), then
+ * resets.  on = 0 switches it off. */
+enum { TD_PROFILE_LAYER_INFER = 1, TD_PROFILE_LAYER_SAVE = 2, TD_PROFILE_BPTT_SWEEP = 4 };
 TD_API int td_profile_enable(int32_t on);
 TD_API int td_profile_read(int32_t *count, float *total_ms);
 

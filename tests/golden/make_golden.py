@@ -375,6 +375,28 @@ def gen_sliced_lse():
     save("sliced_logsumexp", x=np32(x), offsets=np32(offsets), out=np32(ref_mixed.sliced_logsumexp(x, offsets)))
 
 
+CLASSIFIER_CASES = [("lstm", 9, 64, 50, 24), ("gru", 5, 64, 33, 17), ("lstm", 23, 40, 70, 30), ("gru", 9, 256, 40, 12)]
+
+
+def gen_classifier():
+    """the TSTR classifier of the reference itself (evaluate/nn_classifier.py:89-127, RNN): forward
+    probabilities, binary cross entropy (what nnTimeSeriesClassifier.train minimises, :141-142, :158-159) and the gradient
+    of every parameter, for the GPU test to compare td_cls_forward / td_cls_backward with."""
+    import evaluate.nn_classifier as ref_cls
+    assert os.path.realpath(ref_cls.__file__).startswith(os.path.realpath(REF) + os.sep), ref_cls.__file__
+    for model, C, H, B, L in CLASSIFIER_CASES:
+        torch.manual_seed(C + H)
+        net = ref_cls.RNN(in_channels=C, hidden_dim=H, model=model)
+        X = torch.randn(B, C, L)
+        y = (torch.rand(B) > 0.5).float()
+        prob = net(X)
+        loss = torch.nn.functional.binary_cross_entropy(prob, y)
+        loss.backward()
+        arrays = {"sd." + k: np32(v) for k, v in net.state_dict().items()}
+        arrays.update({"grad." + k: np32(v.grad) for k, v in net.named_parameters()})
+        save(f"classifier_{model}_c{C}_h{H}", X=np32(X), y=np32(y), prob=np32(prob), loss=np32(loss), cfg=np.array([C, H, B, L]), **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gen_schedules()
@@ -385,3 +407,4 @@ if __name__ == "__main__":
     gen_sample_chain()
     gen_gaussian()
     gen_train_steps()
+    gen_classifier()

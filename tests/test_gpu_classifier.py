@@ -1,8 +1,10 @@
 """GPU parity of the TSTR classifier (evaluate/nn_classifier.py:89-171) on the recurrent kernels.
 
-The reference class is a stock bidirectional nn.LSTM / nn.GRU + Linear + Sigmoid, so the checker here is that very
-composition in fp32 torch on the CPU with the same weights (a floating-point kernel: torch fp32 is the reference;
-tolerances are the denoiser's: bf16 MFMA operands, fp32 accumulation and state)."""
+The checker is the reference itself: fixtures recorded from its RNN class on the CPU (tests/golden/classifier_*.npz, written
+by tests/golden/make_golden.py: gen_classifier).  Tolerances are the denoiser's: bf16 MFMA operands, fp32 accumulation and
+state."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,60 +19,50 @@ def dev():
     return torch.device("cuda:0")
 
 
-class _TorchRNN(nn.Module):
-    """evaluate/nn_classifier.py:89-127, restated for the CPU check."""
-
-    def __init__(self, in_channels, hidden_dim, model):
-        super().__init__()
-        cls = nn.LSTM if model == "lstm" else nn.GRU
-        setattr(self, model, cls(in_channels, hidden_dim, bidirectional=True, batch_first=True))
-        self.model = model
-        self.final = nn.Sequential(nn.Linear(hidden_dim * 2, 1), nn.Sigmoid())
-
-    def forward(self, X):
-        out, ht = getattr(self, self.model)(X.permute(0, 2, 1))
-        ht = ht[0] if self.model == "lstm" else ht
-        return self.final(ht.permute(1, 0, 2).reshape(X.shape[0], -1)).squeeze(-1)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-@pytest.mark.parametrize("model,C,H,B,L", [("lstm", 9, 64, 50, 24), ("gru", 5, 64, 33, 17), ("lstm", 23, 40, 70, 30), ("gru", 9, 256, 40, 12)])
-def test_classifier_forward_backward(model, C, H, B, L, dev):
+@pytest.mark.parametrize("name", ["classifier_lstm_c9_h64", "classifier_gru_c5_h64", "classifier_lstm_c23_h40", "classifier_gru_c9_h256"])
+def test_classifier_forward_backward(name, dev):
+    """Against the reference's own class: tests/golden/make_golden.py (gen_classifier) imports evaluate/nn_classifier.py
+    from the reference, runs RNN.forward, F.binary_cross_entropy and backward on the CPU and records the weights, inputs,
+    probabilities, loss and every parameter gradient."""
     from evaluate.nn_classifier import RNN
-    torch.manual_seed(C + H)
-    ref = _TorchRNN(C, H, model)
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        g = {k: f[k] for k in f.files}
+    C, H, B, L = [int(v) for v in g["cfg"]]
+    model = "lstm" if "lstm" in name else "gru"
     mine = RNN(in_channels=C, hidden_dim=H, model=model)
-    missing = mine.load_state_dict(ref.state_dict())          # the same keys as the reference's class
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    missing = mine.load_state_dict(sd)          # the same keys as the reference's class
     assert not missing.missing_keys and not missing.unexpected_keys
     mine = mine.to(dev)
-    X = torch.randn(B, C, L)
-    y = (torch.rand(B) > 0.5).float()
-    p_ref = ref(X)
-    loss_ref = nn.functional.binary_cross_entropy(p_ref, y)
-    loss_ref.backward()
+    X, y = torch.from_numpy(g["X"]), torch.from_numpy(g["y"])
+    want = {k[5:]: v for k, v in g.items() if k.startswith("grad.")}
     p = mine(X.to(dev))
     assert p.shape == (B,)
-    assert np.abs(p.detach().cpu().numpy() - p_ref.detach().numpy()).max() < 1e-2
+    assert np.abs(p.detach().cpu().numpy() - g["prob"]).max() < 1e-2
     # through autograd (d loss / d prob from torch's BCE) ...
     loss = nn.functional.binary_cross_entropy(p, y.to(dev))
+    assert abs(float(loss) - float(g["loss"])) < 1e-2
     loss.backward()
-    want = dict(ref.named_parameters())
-    for name, q in mine.named_parameters():
-        assert _rel(q.grad.cpu().numpy(), want[name].grad.numpy()) < 3e-2, (name, _rel(q.grad.cpu().numpy(), want[name].grad.numpy()))
+    assert set(want) == {n for n, _ in mine.named_parameters()}
+    for n, q in mine.named_parameters():
+        assert _rel(q.grad.cpu().numpy(), want[n]) < 3e-2, (n, _rel(q.grad.cpu().numpy(), want[n]))
     # ... and with the BCE derivative fused into the head kernel (what nnTimeSeriesClassifier.train uses)
     with torch.no_grad():
         prob = mine._forward_kernels(X.to(dev))
     fused = mine._backward_kernels(prob, y=y.to(dev))
-    names = [n for n, _ in mine.named_parameters()]
     params = mine._layer_params() + [mine.final[0].weight, mine.final[0].bias]
     by_ptr = {q.data_ptr(): n for n, q in mine.named_parameters()}
-    for g, q in zip(fused, params):
+    assert len(by_ptr) == len(params)
+    for gr, q in zip(fused, params):
         n = by_ptr[q.data_ptr()]
-        assert _rel(g.cpu().numpy(), want[n].grad.numpy()) < 3e-2, n
-    assert len(names) == len(params)
+        assert _rel(gr.cpu().numpy(), want[n]) < 3e-2, n
 
 
 def test_classifier_trains(dev):

@@ -21,6 +21,7 @@ MISC_KEYS = ["time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_
 
 
 LAYER_KERNEL_AUTO, LAYER_KERNEL_BATCH, LAYER_KERNEL_UNITS, LAYER_KERNEL_CLUSTER = 0, 1, 2, 3     # td_set_layer_kernel
+PROFILE_LAYER_INFER, PROFILE_LAYER_SAVE, PROFILE_BPTT_SWEEP = 1, 2, 4     # td_profile_enable
 DW_GEMM_AUTO, DW_GEMM_KERNEL = 0, 1                                     # td_set_dw_gemm
 HEAD_FUSION_AUTO, HEAD_FUSION_OFF, HEAD_FUSION_ON = 0, 1, 2             # td_set_head_fusion
 
@@ -96,6 +97,7 @@ _SIGS = {
     "td_cls_backward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(_P), _P, _P, _P]),
     "td_set_dw_gemm": (C.c_int, [_I]),
     "td_set_head_fusion": (C.c_int, [_I]),
+    "td_check_async_errors": (C.c_int, []),
     "td_profile_enable": (C.c_int, [_I]),
     "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
 }
@@ -129,6 +131,12 @@ def lib():
 def check(rc):
     if rc != 0:
         raise TimediffError(lib().td_last_error().decode())
+
+
+def check_async():
+    """After results have been waited for (a loss read back, samples copied to the host): did a cluster-persistent kernel
+    give up on a hand-off (GPU shared or partitioned: its workgroups were not co-resident)?  Raises instead of handing on NaNs."""
+    check(lib().td_check_async_errors())
 
 
 def ptr(t):

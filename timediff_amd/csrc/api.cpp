@@ -80,9 +80,10 @@ extern "C" int td_profile_enable(int on) {
     return TD_OK;
 }
 
-// called by the recurrent-layer launcher: returns the slot to stop, or -1
-int td_profile_begin(void *stream) {
-    if (!g_prof.on || g_prof.count >= TD_PROF_MAX) return -1;
+// called by the recurrent-layer launchers: returns the slot to stop, or -1.  kind: which launches td_profile_enable asked
+// for (TD_PROFILE_* bits: inference layers above the first, their saving form, the BPTT sweeps of the layers above the first)
+int td_profile_begin(int kind, void *stream) {
+    if (!(g_prof.on & kind) || g_prof.count >= TD_PROF_MAX) return -1;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
     int slot = g_prof.count++;
@@ -107,4 +108,35 @@ extern "C" int td_profile_read(int32_t *count, float *total_ms) {
     if (total_ms) *total_ms = total;
     g_prof.count = 0;
     return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Errors a kernel can only report after the fact.  The cluster-persistent kernels (rnn_cluster.hip, rnn_cluster_bwd.hip)
+// hand data between workgroups inside one launch and need all of them resident at once; where that does not hold (a GPU
+// shared with another process, CU masking) a bounded poll times out, the kernel poisons its outputs with NaN -- and
+// raises this word, which lives in host memory the device can write: td_check_async_errors reads it without touching
+// the GPU.  Allocated by the first td_rnn_pack_weights (never under stream capture).  No counterpart in the reference.
+// ---------------------------------------------------------------------------------------------
+static unsigned *g_async_err = nullptr;
+unsigned *td_async_error_word(bool create) {
+    if (!g_async_err && create) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+            g_async_err = (unsigned *)p;
+            *(volatile unsigned *)g_async_err = 0;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return g_async_err;
+}
+
+extern "C" int td_check_async_errors(void) {
+    if (!g_async_err) return TD_OK;
+    const unsigned v = __atomic_exchange_n(g_async_err, 0u, __ATOMIC_RELAXED);
+    if (v == 0) return TD_OK;
+    td_set_error("a cluster-persistent kernel timed out waiting for another workgroup of its launch (its outputs are NaN): the "
+                 "workgroups were not all resident at once -- is the GPU shared with another process or partitioned? "
+                 "td_set_layer_kernel(TD_LAYER_KERNEL_UNITS) avoids these kernels");
+    return TD_ERR_HIP;
 }

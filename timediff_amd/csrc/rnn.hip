@@ -2,6 +2,7 @@
 // layers (rnn_layer.h) and the LayerNorm + FiLM + fc head.  Reference: models/ETDiff/blocks.py.
 #include "rnn_launch.h"
 #include "rnn_geom.h"
+#include "rnn_cluster.h"
 
 #include <math.h>
 
@@ -194,6 +195,7 @@ extern "C" int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const 
     int rc = td_rnn_geom(cfg, &g);
     if (rc != TD_OK) return rc;
     TD_REQUIRE(lw && packed, "NULL argument");
+    (void)td_async_error_word(true);   // rnn_cluster.h: the word the cluster kernels raise on a timed-out hand-off
     for (int i = 0; i < cfg->layers * cfg->dirs * 4; ++i)
         TD_REQUIRE(lw[i], "NULL weight pointer for layer %d dir %d", i / 4 / cfg->dirs, i / 4 % cfg->dirs);
     TdPackJobs jobs;
@@ -861,7 +863,7 @@ int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool
 int td_rnn_head_wide(const td_rnn_config *cfg, const TdRnnGeom &g, const float *const *misc, const char *act, const float *film,
                      int film_rows, const int32_t *film_row, int batch, int L, float *y, hipStream_t stream);
 
-int td_profile_begin(void *stream);
+int td_profile_begin(int kind, void *stream);
 void td_profile_end(int slot, void *stream);
 
 // Runs pack-input + all recurrent layers.  acts[l] receives layer l's output fragments; saves[l] (training)
@@ -914,18 +916,20 @@ int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const flo
             return TD_ERR_UNSUPPORTED;
         }
         if (td_use_cluster(g, nbb, L)) {
-            const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
+            const int slot = l > 0 ? td_profile_begin(saves ? TD_PROFILE_LAYER_SAVE : TD_PROFILE_LAYER_INFER, stream) : -1;
             rc = td_launch_layer_cluster(cfg->gru, saves ? 1 : 0, g, p, (const char *)packed + g.cl_off[l], g.cl_dir[l == 0 ? 0 : 1],
                                          l == 0, (unsigned long long *)state, stream);
             td_profile_end(slot, stream);
         } else if (td_use_wide(g, nbb)) {
-            const int slot = (l > 0 && !saves) ? td_profile_begin(stream) : -1;
+            const int slot = l > 0 ? td_profile_begin(saves ? TD_PROFILE_LAYER_SAVE : TD_PROFILE_LAYER_INFER, stream) : -1;
             rc = td_launch_layer_wide(cfg->gru, saves ? 1 : 0, g.nu, p, l == 0, g.kx0, stream);
             td_profile_end(slot, stream);
         } else if (saves) {
+            const int slot = l > 0 ? td_profile_begin(TD_PROFILE_LAYER_SAVE, stream) : -1;
             rc = td_launch_layer_save(cfg->gru, g.nu, p, l == 0, kxsel, stream);
+            td_profile_end(slot, stream);
         } else {
-            const int slot = l > 0 ? td_profile_begin(stream) : -1;
+            const int slot = l > 0 ? td_profile_begin(TD_PROFILE_LAYER_INFER, stream) : -1;
             rc = td_launch_layer_infer(cfg->gru, g.nu, p, l == 0, kxsel, stream, head);
             td_profile_end(slot, stream);
         }

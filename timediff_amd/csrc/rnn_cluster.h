@@ -7,6 +7,10 @@
 #define TDC_WAVES 4
 #define TDC_SPIN_LIMIT (1 << 22)
 #define TDC_CUS 256
+unsigned *td_async_error_word(bool create);   // api.cpp
+int td_cluster_device_cus(void);               // rnn_cluster.hip: compute units of the current device (cached), at most TDC_CUS
+// a poll gave up: every lane of the wave stores the same word (system scope: the word is host memory)
+#define TDC_RAISE(p) do { if ((p).err) __hip_atomic_store((p).err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 
 __device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsigned tag) {
     return ((unsigned long long)tag << 32) | payload;
@@ -44,6 +48,7 @@ struct TdClusterBwdParams {
     int L, nbb, dirs, out_frags, H;
     int ngroups;                 // clusters per direction; cluster gi works the batch blocks gi, gi + ngroups, ...
     unsigned epoch;
+    unsigned *err;               // host word raised when a poll times out (api.cpp: td_async_error_word), or NULL
 };
 
 bool td_bptt_cluster_supported(const TdRnnGeom &g, int nbb, int L);

@@ -114,6 +114,7 @@ struct TdClusterParams {
     int in_frags, out_frags, L, nbb, dirs;
     int ngroups;              // clusters per direction; cluster gi works the batch blocks gi, gi + ngroups, ...
     unsigned epoch;
+    unsigned *err;            // host word raised when a poll times out (api.cpp), or NULL
 };
 
 // acc += sum_f W[w0 + f] x (B fragment f of `src`), f < NF: the B fragments come from LDS through a register ring RD deep,
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
 #pragma unroll
                     for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
                     if (ok) break;
-                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
                     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                     for (int n = 0; n < NPOLL; ++n)
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
         unsigned f = fpre;
         while (!dead) {
             if (__builtin_amdgcn_ballot_w64(f != want) == 0) break;
-            if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+            if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
             if (spins > 1) __builtin_amdgcn_s_sleep(1);
             f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -568,6 +569,21 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// Every workgroup of a cluster launch must be resident at once, one per CU: the grid is sized from the device's own count
+// of compute units (a partition or a CU mask the runtime reports shrinks it); a device shared with another process cannot
+// be seen from here -- there the bounded polls time out and td_check_async_errors reports it.
+int td_cluster_device_cus(void) {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TDC_CUS;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = TDC_CUS;
+        cus[dev] = n < TDC_CUS ? n : TDC_CUS;
+    }
+    return cus[dev];
+}
+
 static unsigned g_cluster_epoch = 0;
 unsigned td_cluster_next_epoch(void) { return (++g_cluster_epoch) & 0xFFFFFu; }
 
@@ -585,7 +601,7 @@ size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb) {
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
     // tags carry 12 bits of step index; a parity buffer must have been rewritten by this launch before a step index of the
     // previous launch can recur (L >= 4).  Any batch: a cluster works its batch blocks one after the other within a step.
-    return g.nu == 8 && L >= 4 && L < 4096 && nbb >= 1;
+    return g.nu == 8 && L >= 4 && L < 4096 && nbb >= 1 && td_cluster_device_cus() >= g.nu * g.dirs;
 }
 
 int td_cluster_pack_all(const td_rnn_config *cfg, const TdRnnGeom &g, const float *const *lw, char *packed, hipStream_t stream) {
@@ -643,9 +659,14 @@ int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayer
     // the state scratch follows the exchange buffers of both directions
     p.cstate = (float *)((char *)xch + (size_t)lp.dirs * lp.nbb * 2 * g.nu * TDC_WAVES * 128 * 8);
     // one workgroup per CU, every one resident at once: at most 256 / (NU * dirs) clusters per direction
-    const int max_groups = TDC_CUS / (g.nu * lp.dirs);
+    const int max_groups = td_cluster_device_cus() / (g.nu * lp.dirs);
+    if (max_groups < 1) {
+        td_set_error("cluster kernel: the device has fewer than %d compute units", g.nu * lp.dirs);
+        return TD_ERR_UNSUPPORTED;
+    }
     p.ngroups = lp.nbb < max_groups ? lp.nbb : max_groups;
     p.epoch = td_cluster_next_epoch();
+    p.err = td_async_error_word(false);
     const int blocks = tdc_grid(lp.dirs * p.ngroups, g.nu);
     if (g.nu != 8) {
         td_set_error("cluster kernel: hidden block count %d is not instantiated", g.nu);

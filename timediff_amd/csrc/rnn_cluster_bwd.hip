@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
 #pragma unroll
                     for (int n = 0; n < 2 * NU; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
                     if (ok) break;
-                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
                     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                     for (int n = 0; n < 2 * NU; ++n)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                 while (!dead) {
                     const unsigned f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_ballot_w64(f != want) == 0) break;
-                    if (++spins > TDC_SPIN_LIMIT) { dead = true; break; }
+                    if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 asm volatile("" ::: "memory");      // the payload loads stay behind the poll
@@ -355,12 +355,12 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
 #define TDC_BWD_MAX_BLOCKS 16     // batch blocks per cluster (their carries live in LDS: 4 KiB each)
 
 static int tdc_bwd_groups(const TdRnnGeom &g, int nbb) {
-    const int max_groups = TDC_CUS / (g.nu * g.dirs);      // every workgroup resident at once, one per CU
-    return nbb < max_groups ? nbb : max_groups;
+    const int max_groups = td_cluster_device_cus() / (g.nu * g.dirs);      // every workgroup resident at once, one per CU
+    return nbb < max_groups ? nbb : (max_groups > 1 ? max_groups : 1);
 }
 
 bool td_bptt_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
-    if (!(g.nu == TD_CLUSTER_NU && L >= 4 && L < 4096 && nbb >= 1)) return false;
+    if (!(g.nu == TD_CLUSTER_NU && L >= 4 && L < 4096 && nbb >= 1 && td_cluster_device_cus() >= g.nu * g.dirs)) return false;
     return td_cdiv(nbb, tdc_bwd_groups(g, nbb)) <= TDC_BWD_MAX_BLOCKS;
 }
 
@@ -387,6 +387,7 @@ int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, h
     }
     p.ngroups = tdc_bwd_groups(g, p.nbb);
     p.epoch = td_cluster_next_epoch();
+    p.err = td_async_error_word(false);
     const int blocks = tdc_grid(p.dirs * p.ngroups, g.nu);
     const int nblk = td_cdiv(p.nbb, p.ngroups);
     const size_t shm = 2 * 8 * TD_FRAG_BYTES + (nblk > 1 ? (size_t)nblk * 256 * 16 : 0);

@@ -33,10 +33,28 @@
 #include "rnn_layout.h"
 #include "rnn_params.h"
 
-// diagnostic (tools/kbench): -DTD_ABLATE_MFMA drops the matrix instructions (what the gate math and the memory side cost
-// alone), -DTD_ABLATE_GATES the nonlinearities
+// diagnostics (tools/kbench only; profiles/round3_layer_ablation.md): -DTD_ABLATE_MFMA drops the matrix instructions,
+// -DTD_ABLATE_GATES the nonlinearities, -DTD_ABLATE_DMA the LDS-DMA pieces, -DTD_ABLATE_LDSREAD the LDS reads of the weight
+// fragments, -DTD_ABLATE_WAIT / -DTD_ABLATE_BARRIER the stage boundary's wait / barrier, -DTD_ABLATE_MFMA16 issues the
+// matrix work as 16x16x32.  None of them computes the layer; none is defined in the library build.
 #ifdef TD_ABLATE_MFMA
 #define TD_MFMA(a, b, c) (c)
+#elif defined(TD_ABLATE_MFMA16)
+// diagnostic (tools/kbench; results are NOT the layer's): the same operand traffic issued as v_mfma_f32_16x16x32_bf16 -- one
+// A fragment from LDS feeds two matrix instructions of 16 x 16 x 32 (what a 16-unit x 32-k weight fragment against two
+// 16-sequence tiles would do), each accumulating into its own quarter of the slot's accumulator; `f` is the slot index
+// of the enclosing schedule.  Same FLOPs, LDS bytes, DMA and gate math per step as the shipped kernel.
+template <int P>
+__device__ __forceinline__ f32x16 td_mfma16_pair(bf16x8 a, bf16x8 b, f32x16 c) {
+    f32x4 q0 = {c[8 * P], c[8 * P + 1], c[8 * P + 2], c[8 * P + 3]};
+    f32x4 q1 = {c[8 * P + 4], c[8 * P + 5], c[8 * P + 6], c[8 * P + 7]};
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, q1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[8 * P + i] = q0[i]; c[8 * P + 4 + i] = q1[i]; }
+    return c;
+}
+#define TD_MFMA(a, b, c) td_mfma16_pair<(f & 1)>(a, b, c)
 #else
 #define TD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif
@@ -73,16 +91,6 @@ __device__ __forceinline__ float td_unpark(float a) {
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
     return v;
 }
-
-
-// A/B switch (TdSched::CARRY): 1 = the gate math of a step's last block rides in the next step's block 0 instead of running
-// in the open behind its own step.  Measured at the bench shape: correct (the whole GPU suite passes)
-// and 1 % SLOWER: 54.5 instead of 52.6 cycles per MFMA at an unchanged clock -- block 0 has only 60 slots that do not read the
-// last block's h, and 3 to 5 dependent micro-ops in front of each of their MFMAs stall the in-order issue.  Off until the
-// stream order gives block 0 enough independent slots (input k-steps before the last two recurrent ones).
-#ifndef TD_CARRY_TAIL
-#define TD_CARRY_TAIL 0
-#endif
 
 #define TD_RING_FRAGS 8   // weight fragments per ring stage
 #define TD_RING_DEPTH 4   // ring stages
@@ -124,14 +132,7 @@ struct TdSched {
     // from.  Every read of stage j - 2 has been consumed by an MFMA issued before stage j opens (the register
     // ring holds 8 = one stage of fragments), so no wave needs to drain its LDS reads at the boundary.
     static constexpr int LEAD = TD_RING_DEPTH - 2;
-    static constexpr int PIECE_STEP = 2;  // pieces go out at positions 1, 3
-    // CARRY: the gate math of a step's LAST block has no later block of that step to hide behind (192 micro-ops = 1.4 us
-    // per step in the open: 6 % of the first layer, 3 % of an upper one).  The next step's block 0 takes it: its bias
-    // slots and its recurrent slots for k-steps 0 .. KH - 3 read nothing the last block produces (h of the last block's
-    // units is k-steps KH - 2, KH - 1), and with NU even block 0 accumulates into the other accumulator set.  Step 0
-    // carries the gates of an all-zero accumulator set over a zero state, which is exactly the initial state again.
-    static constexpr bool CARRY = TD_CARRY_TAIL && !SAVE && !HEAD && NU % 2 == 0;
-    static constexpr int CARRY_SLOTS = 4 + (KH - 2) * NG;
+    static constexpr int PIECE_STEP = 2;  // pieces go out at positions 1, 3 (both in one slot, back to back: +1.7 cycles per fragment)
     static_assert(T::APD <= TD_RING_FRAGS, "the LDS read ring must not reach back two stages");
 
     // weight fragment whose LDS read is issued in slot F (-1: none)
@@ -166,7 +167,7 @@ struct TdSched {
     static constexpr bool boundary(int F) { return refill_of(F) >= 0 && refill_of(F) % TD_RING_FRAGS == 0; }
     // room for gate-math micro-ops beside slot F's MFMA (block 0 of a step has no previous block to finish)
     static constexpr int capacity(int F) {
-        if (F / FU == 0 && (!CARRY || F >= CARRY_SLOTS)) return 0;
+        if (F / FU == 0) return 0;
         // head slots: the last four multiply the last block's own h_t, i.e. follow every one of its gate micro-ops
         if (F >= NFB && F - NFB >= HF - 4) return 0;
         if (boundary(F)) return 0;  // wait + barrier
@@ -255,6 +256,10 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
     const unsigned lane16 = lane * 16;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
     auto dma = [&](const char *src, unsigned dst) {
+#ifdef TD_ABLATE_DMA
+        // diagnostic (tools/kbench): no LDS-DMA at all, the MFMAs read whatever the LDS holds -- what issuing the pieces costs
+        return;
+#endif
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lane16), "s"(src) : "memory");
     };
     // weights: ring stage j (any step) = fragments 8j .. 8j+7 of the packed stream, wave w moves 2w, 2w+1
@@ -304,15 +309,6 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) hold[ks] = zero;
     }
-    // CARRY: where the carried block's h goes.  Step 0 carries nothing real: its two stores (they are part of the counted
-    // vector-memory stream) write zeros to the row this wave writes last, long before that row's own store.
-    char *opc = p.out + (((size_t)(dir ? 0 : p.L - 1) * p.nbb + bb) * p.out_frags + dir * KH) * TD_FRAG_BYTES + lane * 16;
-    if constexpr (S::CARRY) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[(NU - 1) & 1][g][r] = 0.f;
-    }
 
     for (int s = 0; s < p.L; ++s) {
         const int l = dir ? p.L - 1 - s : s;
@@ -345,12 +341,22 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 // my pieces of `stage` have landed (younger loads/stores may stay in flight); after the barrier
                 // that holds for every wave, and every wave is done with the buffer the next pieces go to
                 constexpr int WN = S::tab.waitn[stage];
+#ifndef TD_ABLATE_WAIT
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN) : "memory");
+#endif
+#ifndef TD_ABLATE_BARRIER
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("" ::: "memory");
                 ring = (ring + 1) & (TD_RING_DEPTH - 1);
             }
+#ifdef TD_ABLATE_LDSREAD
+            // diagnostic (tools/kbench): the weight fragments are not read from LDS at all (what the LDS reads cost)
+            bf16x8 a = ones;
+            asm volatile("" : "+v"(a));
+#else
             const bf16x8 a = *(const bf16x8 *)(lds + ring * TD_RING_BYTES + pos * TD_FRAG_BYTES + lane * 16);
+#endif
             td_static_for<T::PIECES>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (S::piece_pos(stage, i) == pos) {
@@ -366,10 +372,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
         // micro-op q of block ub's gate nonlinearities; rows go in pairs so that the dependent exp -> rcp -> fma
         // chain of one row is separated by the other row's instructions.
         // row r of the accumulator = unit 32u + (r&3) + 8(r>>2) + 4hf
-        auto gate_op = [&](auto ubc, auto qc, auto carried) {
+        auto gate_op = [&](auto ubc, auto qc) {
             constexpr int ub = decltype(ubc)::value, q = decltype(qc)::value;
-            constexpr bool CARRIED = decltype(carried)::value;   // the previous step's last block, finished inside this step's block 0
-            auto &hdst = [&]() -> bf16x8(&)[KH] { if constexpr (CARRIED) return hold; else return hn; }();
             constexpr int pair = q / (2 * NOPS), w = q % (2 * NOPS), o = w / 2, r = 2 * pair + (w & 1);
             constexpr float P2L2E = TD_GATE_SCALE_TANH;
             f32x16(&a)[4] = acc[ub & 1];
@@ -433,8 +437,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                 if constexpr ((r & 1) == 0) hprev = hval;
                 else {
                     const __bf16 b0 = (__bf16)hprev, b1 = (__bf16)hval;
-                    hdst[2 * ub + (r >> 3)][(r & 7) - 1] = b0;
-                    hdst[2 * ub + (r >> 3)][r & 7] = b1;
+                    hn[2 * ub + (r >> 3)][(r & 7) - 1] = b0;
+                    hn[2 * ub + (r >> 3)][r & 7] = b1;
                     if constexpr (HEAD) {
                         const float f0 = (float)b0, f1 = (float)b1;
                         hs1 += f0 + f1;
@@ -445,9 +449,8 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             if constexpr (q == NQ - 1 && !HEAD) {
                 // h_t of this block goes to HBM for the next layer right away (streaming store: it must not push
                 // the weights out of this XCD's L2)
-                char *o = CARRIED ? opc : op;
-                __builtin_nontemporal_store(hdst[2 * ub], (bf16x8 *)(o + (2 * ub) * TD_FRAG_BYTES));
-                __builtin_nontemporal_store(hdst[2 * ub + 1], (bf16x8 *)(o + (2 * ub + 1) * TD_FRAG_BYTES));
+                __builtin_nontemporal_store(hn[2 * ub], (bf16x8 *)(op + (2 * ub) * TD_FRAG_BYTES));
+                __builtin_nontemporal_store(hn[2 * ub + 1], (bf16x8 *)(op + (2 * ub + 1) * TD_FRAG_BYTES));
             }
         };
 
@@ -510,14 +513,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
                     td_static_for<q1 - q0>([&](auto jc) {
                         gate_op(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{},
-                                std::integral_constant<int, q0 + decltype(jc)::value>{}, std::false_type{});
-                    });
-                } else if constexpr (S::CARRY) {
-                    // the previous step's last block (step 0: zeros over zeros)
-                    constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
-                    td_static_for<q1 - q0>([&](auto jc) {
-                        gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{},
-                                std::true_type{});
+                                std::integral_constant<int, q0 + decltype(jc)::value>{});
                     });
                 }
                 // pin the slot: left alone, the scheduler sinks every ds_read next to its MFMA and piles the
@@ -526,19 +522,15 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
             });
         });
 
-        if constexpr (S::CARRY) {
-            // the last block's gates ride in the next step's block 0; only the last step finishes them here
-            opc = op;
-            if (last_step) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc, std::true_type{}); });
-        } else if constexpr (!HEAD) {
+        if constexpr (!HEAD) {
             // the last block's gates have no MFMAs left to hide behind
-            td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc, std::false_type{}); });
+            td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
         } else {
             // head slots: partial projection of h_t, k-step by k-step (hi and lo part of the folded weights); the k-steps of
             // the blocks before the last run beside the last block's gate math, the last block's own four slots after it
             f32x16 &hacc = acc[NU & 1][0];     // the accumulator set the last block does not use
             // a single unit block: every head slot multiplies that block's own h_t, its gate math has nothing to hide behind
-            if constexpr (HF <= 4) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc, std::false_type{}); });
+            if constexpr (HF <= 4) td_static_for<NQ>([&](auto qc) { gate_op(std::integral_constant<int, NU - 1>{}, qc); });
             td_static_for<HF>([&](auto fc) {
                 constexpr int f = decltype(fc)::value;
                 constexpr int F = NFB + f;
@@ -552,8 +544,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
                     A[F % APD] = refill(std::integral_constant<int, (S::refill_of(F) >= 0 ? S::refill_of(F) : 0)>{});
                 constexpr int q0 = S::tab.qbeg[F], q1 = S::tab.qend[F];
                 td_static_for<q1 - q0>([&](auto jc) {
-                    gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{},
-                            std::false_type{});
+                    gate_op(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, q0 + decltype(jc)::value>{});
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -570,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_layer_kernel(TdLayerParams p) {
 
         // h_t replaces h_{t-1} only now: every unit block above consumed the old one
 #pragma unroll
-        for (int ks = 0; ks < (S::CARRY ? KH - 2 : KH); ++ks) hold[ks] = hn[ks];
+        for (int ks = 0; ks < KH; ++ks) hold[ks] = hn[ks];
     }
     // no LDS-DMA piece may still be in flight when the workgroup's LDS is handed on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -21,19 +21,8 @@ constexpr bool td_sched_ok() {
         }
         if (q != S::NQ) return false;
     }
-    if (!S::CARRY) {
-        for (int f = 0; f < T::FU; ++f)
-            if (S::tab.qbeg[f] != S::tab.qend[f]) return false;   // block 0 carries none
-    } else {
-        // block 0 finishes the previous step's last block, in order, before its first slot that reads that block's h
-        int q = 0;
-        for (int f = 0; f < T::FU; ++f) {
-            if (S::tab.qbeg[f] != q || S::tab.qend[f] < q) return false;
-            q = S::tab.qend[f];
-            if (f >= S::CARRY_SLOTS && S::tab.qbeg[f] != S::NQ) return false;
-        }
-        if (q != S::NQ) return false;
-    }
+    for (int f = 0; f < T::FU; ++f)
+        if (S::tab.qbeg[f] != S::tab.qend[f]) return false;   // block 0 carries none
     if (HEAD) {   // the head slots finish the last block's micro-ops, in order, before the last four of them
         int q = T::HF > 4 ? 0 : S::NQ;   // a single unit block: the kernel runs its gate math in front of the head slots
         for (int f = 0; f < T::HF; ++f) {

@@ -15,6 +15,9 @@
 #include "rnn_launch.h"
 #include "rng.h"
 
+int td_profile_begin(int kind, void *stream);   // api.cpp
+void td_profile_end(int slot, void *stream);
+
 int td_launch_layer_save(int gru, int nu, const TdLayerParams &p, bool layer0, int kxsel, hipStream_t stream) {
     return td_launch_layer_dispatch(gru, 1, nu, p, layer0, kxsel, stream);
 }
@@ -1349,6 +1352,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
             q.wt = wT; q.wt_dir = packT_dir; q.nterm = G;
             q.slab[0] = 0; q.slab[1] = 1; q.slab[2] = cfg->gru ? 3 : 2; q.slab[3] = 3;
             const int mode = td_layer_kernel_mode();
+            const int prof_slot = l > 0 ? td_profile_begin(TD_PROFILE_BPTT_SWEEP, stream) : -1;
             if ((mode == TD_LAYER_KERNEL_AUTO || mode == TD_LAYER_KERNEL_CLUSTER) && td_bptt_cluster_supported(g, t.nbb, L)) {
                 TdClusterBwdParams cp;
                 cp.gsrc[0] = p.gsrc[0]; cp.gsrc[1] = p.gsrc[1]; cp.n_src = n_src;
@@ -1370,6 +1374,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
             } else {
                 hipLaunchKernelGGL((td_bptt_sweep_kernel<4, true>), D == 2 ? dim3(8 * td_cdiv(t.nbb, 4)) : dim3(t.nbb, 1), dim3(512), 0, stream, q);
             }
+            td_profile_end(prof_slot, stream);
             TD_LAUNCH_CHECK();
         }
         // gradient for the layer below: d x = W_ih^T d a, all steps at once

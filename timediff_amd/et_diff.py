@@ -447,6 +447,7 @@ class ETDiff(nn.Module):
             while self.step < self.diff_num_steps:
                 loss = self.train_step()
                 total_loss = (pending if pending is not None else loss).item()
+                _lib.check_async()      # the read-back waited for that step's kernels
                 pending = loss
                 pbar.set_description(f"loss: {total_loss:.4f}")
                 if exists(self.wandb) and self.timer() - last_log > 60:

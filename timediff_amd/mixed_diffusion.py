@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .ops import DiffusionKernels, SamplerKernels
 from .schedule import make_tables
 
@@ -133,4 +134,7 @@ class MixedDiffusion(nn.Module):
             self._film_version = version
         out = self._sampler.sample(batch_size, noise, uniforms, seed=_fresh_seed() if seed is None else seed,
                                    patient0=patient0)
-        return out.cpu() if to_cpu else out
+        if to_cpu:
+            out = out.cpu()
+            _lib.check_async()      # the copy waited for the chain's kernels
+        return out
