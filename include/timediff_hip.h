@@ -14,9 +14,10 @@
  *     native layout (LSTM gate rows i,f,g,o; GRU gate rows r,z,n);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
  *     enqueues work and takes its scratch through the `workspace` arguments sized by the matching
- *     *_bytes() query.  Exceptions, each once per process: td_rnn_backward[_cb], td_cls_backward and (from 256 rows
- *     up) td_rnn_time_film_backward create a rocBLAS handle (which owns a device workspace) on the first such call; td_sample_chain instantiates and caches a
- *     hipGraph (released by td_sample_chain_release); td_profile_enable creates HIP events;
+ *     *_bytes() query.  Exceptions, each once per process: td_sample_chain instantiates and caches a hipGraph
+ *     (released by td_sample_chain_release); td_profile_enable creates HIP events; the first td_rnn_pack_weights
+ *     allocates 64 bytes of device-writable host memory (td_check_async_errors).  The library links no vendor
+ *     math library: every GEMM on the path is a kernel of this tree;
  *   - limits of this build: hidden <= 1024, c_in <= 32, c_out <= 32, at most TD_MAX_CAT discrete variables
  *     of at most TD_MAX_CLASSES classes each (the reference accepts any K_i, mixed_diffusion.py:44-51);
  *   - return value: TD_OK or an error code; td_last_error() returns the message (thread-local).
@@ -303,16 +304,12 @@ TD_API int td_cls_backward(const td_rnn_config *cfg, const void *packT, const fl
  *     UNITS / CLUSTER force one family (UNITS needs hidden > 32; CLUSTER is an error where it cannot run).  The same
  *     mode steers the BPTT sweep of td_rnn_backward: AUTO / CLUSTER take the cluster sweep of rnn_cluster_bwd.hip
  *     where it can run (hidden 193..256, at most 16 batch blocks per cluster = 8192 bidirectional sequences), BATCH /
- *     UNITS the single-workgroup sweep.
- *   td_set_dw_gemm: weight-gradient GEMMs.  AUTO = rocBLAS where the shape has no column remap, the in-tree
- *     split-K MFMA kernel otherwise; KERNEL = the in-tree kernel for every shape. */
+ *     UNITS the single-workgroup sweep. */
 enum { TD_LAYER_KERNEL_AUTO = 0, TD_LAYER_KERNEL_BATCH = 1, TD_LAYER_KERNEL_UNITS = 2, TD_LAYER_KERNEL_CLUSTER = 3 };
-enum { TD_DW_GEMM_AUTO = 0, TD_DW_GEMM_KERNEL = 1 };
 TD_API int td_set_layer_kernel(int32_t mode);
 /* Which family a (cfg, batch, seq_len) launch takes under the current mode: TD_LAYER_KERNEL_BATCH, _UNITS or _CLUSTER
  * (-1: bad cfg, or a forced family that cannot run this shape). */
 TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
-TD_API int td_set_dw_gemm(int32_t mode);
 /* The sampler's head (LayerNorm + FiLM + fc with one FiLM row for the whole batch) fused into the top layer's kernel: the
  * layer leaves per-direction partial projections and sum h, sum h^2 instead of its activations (csrc/rnn.hip).  AUTO:
  * td_sample_chain fuses wherever the batch-block kernel family runs the layers (large batches, at least two layers),

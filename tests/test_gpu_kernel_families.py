@@ -285,6 +285,27 @@ def test_cluster_several_blocks_per_cluster(gru, dirs, B, dev, knob):
     _check_forward_and_grads(den, sd, x, t, gy, rows, dev)
 
 
+@pytest.mark.parametrize("T", [1, 2, 5, 11])
+def test_single_layer_cluster_chain_graph_equals_stepwise(T, dev):
+    """One recurrent layer at the cluster family's shape: a captured reverse step would hold a single cluster launch, whose
+    hand-off tags carry the launch epoch baked into the graph.  The chain captures two steps per graph below eight (and
+    none for T = 1), so that consecutive launches on one exchange buffer never share an epoch: replayed chains equal the
+    eager chain bit for bit, also when the same cached graph runs a second chain."""
+    from timediff_amd import _lib
+    from timediff_amd.ops import DiffusionKernels, SamplerKernels
+    H, L, B = 256, 9, 70
+    num, cat, K = [0, 2, 4, 6], [1, 3, 5, 7, 8], [2] * 5
+    sd = random_state(H, 14, 1, 2, 0, seed=5)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_CLUSTER
+    tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
+    sampler = SamplerKernels(den, DiffusionKernels(num, cat, K, L, T, tables, 9, dev))
+    eager = sampler.sample(B, seed=3, patient0=10, use_graph=False)
+    assert torch.isfinite(eager).all()
+    for _ in range(3):
+        assert torch.equal(sampler.sample(B, seed=3, patient0=10), eager)
+
+
 def test_cluster_dispatch_and_agreement(dev, knob):
     """AUTO takes the cluster kernel where it can run (hidden 193..256, at most 2048 sequences bidirectional, at least 4
     steps) and nothing else; its results agree with the unit-split kernel's within the bf16 bound, run to run

@@ -209,6 +209,23 @@ def test_dataset_streamed_build_equals_in_memory(tmp_path, monkeypatch):
         D.TimeSeriesDataset("other", [3], 9, load_path=str(tmp_path / "missing.pt"), root=str(tmp_path / "datasets"))
 
 
+def test_dataset_build_with_a_constant_channel(tmp_path, monkeypatch):
+    """A channel whose max equals its min normalises to 0 / 0 = NaN; the reference's normalize_data (utils.py:143) leaves
+    NaNs out of its range check and builds the cache, and so does the streamed build -- with the same values."""
+    from timediff_amd import data as D
+    torch.manual_seed(4)
+    raw = torch.randn(20, 4, 6)
+    raw[:, 2, :] = 3.5
+    torch.save(raw, tmp_path / "raw.pt")
+    monkeypatch.setattr(D.TimeSeriesDataset, "CHUNK", 6)
+    ds = D.TimeSeriesDataset("const", None, 6, load_path=str(tmp_path / "raw.pt"), root=str(tmp_path / "datasets"))
+    want, lo, hi = D.normalize_data(D.replace_nan_with_mean(raw), None)
+    assert torch.isnan(ds.data[:, 2]).all() and torch.isnan(want[:, 2]).all()
+    rest = [0, 1, 3]
+    assert torch.allclose(ds.data[:, rest], want[:, rest], rtol=0, atol=2e-6)
+    assert torch.allclose(ds.min, lo, atol=1e-6) and torch.allclose(ds.max, hi, atol=1e-6)
+
+
 def test_layer_slices_and_uncovered_ranges():
     """The flat gradient buffer's per-layer all-reduce slices (ETDiff._layer_reduce) and what is left for the end."""
     import torch.nn as nn

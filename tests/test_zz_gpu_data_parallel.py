@@ -13,7 +13,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _dp_worker(rank, world, port, overlap, out_path, backend="gloo", force=0):
+def _dp_worker(rank, world, port, overlap, out_path, backend="gloo", force=0, hidden=32, layers=3):
     """One data-parallel rank (both ranks share GPU 0; gloo moves the CUDA gradient slices).  backend="nccl" with
     world = 1 and force = 1: the production RCCL branch on a single-rank communicator."""
     import faulthandler
@@ -31,7 +31,7 @@ def _dp_worker(rank, world, port, overlap, out_path, backend="gloo", force=0):
     from models.ETDiff.mixed_diffusion import MixedDiffusion
     from timediff_amd.data import TensorSeriesDataset
     torch.manual_seed(0)          # same initial weights on every rank
-    rnn = RNN(input_channels=7, hidden_channels=32, output_channels=7, layers=3, model="lstm", bidirectional=True)
+    rnn = RNN(input_channels=7, hidden_channels=hidden, output_channels=7, layers=layers, model="lstm", bidirectional=True)
     diff = MixedDiffusion(rnn, seq_length=12, channels=7, numerical_features_indices=[0, 2, 3],
                           categorical_features_indices=[1, 4], categorical_num_classes=[2, 2], timesteps=20, loss_lambda=0.8)
     data = torch.rand(64, 5, 12)
@@ -54,7 +54,7 @@ def _dp_worker(rank, world, port, overlap, out_path, backend="gloo", force=0):
     assert (mine != init.cpu()).float().mean() > 0.99 and all(l == l for l in losses)
     if force:
         assert dist.is_initialized() and dist.get_backend() == backend and et._dp
-        want = 2 * (3 + 1 if overlap else 1)      # per optimizer step: 3 layer slices + the rest, or one whole-buffer reduce
+        want = 2 * (layers + 1 if overlap else 1)      # per optimizer step: a slice per layer + the rest, or one whole-buffer reduce
         assert len(reduced) >= want, (len(reduced), want)
     if rank == 0:
         torch.save({"param": mine, "losses": losses}, out_path)
@@ -63,11 +63,11 @@ def _dp_worker(rank, world, port, overlap, out_path, backend="gloo", force=0):
         dist.destroy_process_group()
 
 
-def _run_dp(tmp_path, overlap, port, world=2, backend="gloo", force=0):
+def _run_dp(tmp_path, overlap, port, world=2, backend="gloo", force=0, hidden=32, layers=3):
     import torch.multiprocessing as mp
-    out = str(tmp_path / f"dp_{backend}_w{world}_f{force}_overlap{overlap}.pt")
+    out = str(tmp_path / f"dp_{backend}_w{world}_f{force}_overlap{overlap}_h{hidden}.pt")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, overlap, out, backend, force)) for r in range(world)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, overlap, out, backend, force, hidden, layers)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -106,3 +106,17 @@ def test_nccl_branch_single_rank_equals_plain(dev, tmp_path):
     plain = _run_dp(tmp_path, 1, port + 1, world=1, backend="nccl", force=0)
     assert torch.allclose(forced["param"], plain["param"], rtol=0, atol=2e-5), float((forced["param"] - plain["param"]).abs().max())
     np.testing.assert_allclose(forced["losses"], plain["losses"], rtol=1e-4)
+
+
+def test_data_parallel_two_ranks_wide_hidden(dev, tmp_path):
+    """BASELINE.json configs[4] in miniature: data-parallel training of a WIDE-hidden denoiser (H = 512: rnn_wide.hip, the wide
+    BPTT sweep, 13 M parameters in the flat gradient buffer), two ranks on this GPU, per-layer all-reduces started from inside
+    the backward pass.  The worker asserts that both ranks hold bit-identical weights after two optimizer steps; here the
+    overlapped exchange must also give the weights of the single all-reduce after the backward pass."""
+    import os
+    port = 29300 + os.getpid() % 1000
+    a = _run_dp(tmp_path, 1, port, hidden=512, layers=2)
+    b = _run_dp(tmp_path, 0, port + 1, hidden=512, layers=2)
+    assert torch.isfinite(a["param"]).all()
+    assert torch.allclose(a["param"], b["param"], rtol=0, atol=2e-5), float((a["param"] - b["param"]).abs().max())
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-4)

@@ -22,7 +22,6 @@ MISC_KEYS = ["time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_
 
 LAYER_KERNEL_AUTO, LAYER_KERNEL_BATCH, LAYER_KERNEL_UNITS, LAYER_KERNEL_CLUSTER = 0, 1, 2, 3     # td_set_layer_kernel
 PROFILE_LAYER_INFER, PROFILE_LAYER_SAVE, PROFILE_BPTT_SWEEP = 1, 2, 4     # td_profile_enable
-DW_GEMM_AUTO, DW_GEMM_KERNEL = 0, 1                                     # td_set_dw_gemm
 HEAD_FUSION_AUTO, HEAD_FUSION_OFF, HEAD_FUSION_ON = 0, 1, 2             # td_set_head_fusion
 
 
@@ -95,7 +94,6 @@ _SIGS = {
     "td_cls_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
     "td_cls_forward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "td_cls_backward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(_P), _P, _P, _P]),
-    "td_set_dw_gemm": (C.c_int, [_I]),
     "td_set_head_fusion": (C.c_int, [_I]),
     "td_check_async_errors": (C.c_int, []),
     "td_profile_enable": (C.c_int, [_I]),
@@ -123,8 +121,6 @@ def lib():
         mode = os.environ.get("TIMEDIFF_LAYER_KERNEL", "")
         if mode[:1] in ("b", "u", "c"):
             handle.td_set_layer_kernel({"b": LAYER_KERNEL_BATCH, "u": LAYER_KERNEL_UNITS, "c": LAYER_KERNEL_CLUSTER}[mode[0]])
-        if os.environ.get("TIMEDIFF_DW_GEMM", "")[:1] == "k":
-            handle.td_set_dw_gemm(DW_GEMM_KERNEL)
     return _lib
 
 

@@ -15,8 +15,13 @@ class _DenoiserFn(torch.autograd.Function):
         # torch.manual_seed makes a run repeatable; the backward pass re-sets the same (p, seed)
         p = module.dropout if module.training else 0.0
         ctx.dropout = (p, int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+        # (p, seed) is process-wide state of the library that also sizes the training workspace: it holds for this call
+        # only, so that a later direct forward_train / backward caller (tests, the bench, C-ABI users) never inherits it
         k.set_dropout(*ctx.dropout)
-        y = k.forward_train(x, film)
+        try:
+            y = k.forward_train(x, film)
+        finally:
+            k.set_dropout(0.0)
         ctx.module = module
         ctx.save_for_backward(film, time)
         return y
@@ -26,6 +31,13 @@ class _DenoiserFn(torch.autograd.Function):
         film, time = ctx.saved_tensors
         k = ctx.module.kernels()
         k.set_dropout(*ctx.dropout)
+        try:
+            return _DenoiserFn._backward_body(ctx, k, grad_y, film, time)
+        finally:
+            k.set_dropout(0.0)
+
+    @staticmethod
+    def _backward_body(ctx, k, grad_y, film, time):
         sink = getattr(ctx.module, "_grad_sink", None)
         if sink is not None:
             # the trainer's flat gradient buffer: the kernels accumulate straight into the .grad views (no

@@ -195,9 +195,15 @@ class nnTimeSeriesClassifier:
             self.train_step()
 
     def change_device(self, device):
-        if torch.device(device).type != "cuda":
+        """nn_classifier.py:163-165 moves the model.  Here the model's parameters are views of flat buffers on the device the
+        classifier was built on, the kernels have no CPU form, and nothing in the reference calls this with another
+        accelerator: the current device is accepted, anything else is refused rather than half-done."""
+        target = torch.device(device)
+        if target.type != "cuda":
             raise RuntimeError("the classifier runs on the MI355X only")
-        self.device = torch.device(device)
+        if target.index is not None and target.index != (self.device.index if self.device.index is not None else torch.cuda.current_device()):
+            raise NotImplementedError(f"the classifier was built on {self.device}; build a new one on {target} (its parameters are "
+                                      "views of flat device buffers)")
 
     @torch.no_grad()
     def predict_proba(self, X):

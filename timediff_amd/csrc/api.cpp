@@ -20,11 +20,9 @@ extern "C" int td_version(void) { return 200; }
 // Explicit kernel-selection knobs (tests and measurements flip them in-process).  No counterpart in the reference.
 // ---------------------------------------------------------------------------------------------
 static int g_layer_kernel = TD_LAYER_KERNEL_AUTO;
-static int g_dw_gemm = TD_DW_GEMM_AUTO;
 static int g_head_fusion = TD_HEAD_FUSION_AUTO;
 int td_head_fusion_mode(void) { return g_head_fusion; }
 int td_layer_kernel_mode(void) { return g_layer_kernel; }
-int td_dw_gemm_mode(void) { return g_dw_gemm; }
 
 extern "C" int td_set_head_fusion(int32_t mode) {
     if (mode != TD_HEAD_FUSION_AUTO && mode != TD_HEAD_FUSION_OFF && mode != TD_HEAD_FUSION_ON) {
@@ -41,14 +39,6 @@ extern "C" int td_set_layer_kernel(int32_t mode) {
         return TD_ERR_INVALID;
     }
     g_layer_kernel = mode;
-    return TD_OK;
-}
-extern "C" int td_set_dw_gemm(int32_t mode) {
-    if (mode != TD_DW_GEMM_AUTO && mode != TD_DW_GEMM_KERNEL) {
-        td_set_error("td_set_dw_gemm: unknown mode %d", mode);
-        return TD_ERR_INVALID;
-    }
-    g_dw_gemm = mode;
     return TD_OK;
 }
 

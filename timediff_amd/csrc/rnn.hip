@@ -377,19 +377,49 @@ __global__ __launch_bounds__(TD_FILM_BWD_THREADS) void td_time_film_bwd_rows_ker
     for (int kk = tid; kk < E; kk += nth) row[kk] = sinus[kk];
 }
 
-#define TD_OUTER_LIB_MIN_ROWS 256
-int td_outer_sum_lib(const float *left, size_t lstride, const float *right, size_t rstride, float *dw, int R, int K, int n,
-                     hipStream_t stream);   // gemm_lib.cpp
-
-// d W[r][k] += sum_i left[i][r] * right[i][k]   (left / right: columns of the per-row records, or d film)
+// d W[r][k] += sum_i left[i][r] * right[i][k]   (left / right: columns of the per-row records, or d film; fp32)
+// A workgroup owns a 64 x 64 tile of d W (a thread 4 x 4 of it) and walks the rows i in stages of 32 through LDS; a tile
+// is summed in row order by one workgroup (from 256 rows up several, which add with float atomics).  The weight gradients of the
+// time-embedding MLP and the FiLM linear: at most 1024 x 256 outputs over `batch` rows, 1 GFLOP at batch 2048.
+#define TD_OS_TILE 64
+#define TD_OS_ROWS 32
 __global__ __launch_bounds__(256) void td_outer_sum_kernel(const float *__restrict__ left, size_t lstride, const float *__restrict__ right,
                                                             size_t rstride, float *__restrict__ dw, int R, int K, int n) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)R * K) return;
-    const int r = (int)(idx / K), k = (int)(idx % K);
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(left[(size_t)i * lstride + r], right[(size_t)i * rstride + k], acc);
-    dw[idx] += acc;
+    __shared__ float sl[TD_OS_ROWS][TD_OS_TILE + 4], sr[TD_OS_ROWS][TD_OS_TILE + 4];
+    const int r0 = blockIdx.x * TD_OS_TILE, k0 = blockIdx.y * TD_OS_TILE;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    float acc[4][4] = {};
+    // gridDim.z > 1: the rows are cut into chunks that add into d W with float atomics (large batches only)
+    const int per = TD_OS_ROWS * ((n + TD_OS_ROWS * (int)gridDim.z - 1) / (TD_OS_ROWS * (int)gridDim.z));
+    const int ibeg = blockIdx.z * per, iend = min(n, ibeg + per);
+    for (int i0 = ibeg; i0 < iend; i0 += TD_OS_ROWS) {
+        for (int e = tid; e < TD_OS_ROWS * TD_OS_TILE; e += 256) {
+            const int ii = e / TD_OS_TILE, cc = e % TD_OS_TILE;
+            const bool row = i0 + ii < iend;
+            sl[ii][cc] = (row && r0 + cc < R) ? left[(size_t)(i0 + ii) * lstride + r0 + cc] : 0.f;
+            sr[ii][cc] = (row && k0 + cc < K) ? right[(size_t)(i0 + ii) * rstride + k0 + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int ii = 0; ii < TD_OS_ROWS; ++ii) {
+            const f32x4 a = *(const f32x4 *)&sl[ii][4 * ty], b = *(const f32x4 *)&sr[ii][4 * tx];
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[y][x] = fmaf(a[y], b[x], acc[y][x]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int r = r0 + 4 * ty + y, k = k0 + 4 * tx + x;
+            if (r < R && k < K) {
+                if (gridDim.z > 1) atomicAdd(&dw[(size_t)r * K + k], acc[y][x]);
+                else dw[(size_t)r * K + k] += acc[y][x];
+            }
+        }
 }
 
 extern "C" size_t td_rnn_time_film_backward_workspace_bytes(const td_rnn_config *cfg, int32_t n_t) {
@@ -418,12 +448,13 @@ extern "C" int td_rnn_time_film_backward(const td_rnn_config *cfg, const float *
     TD_LAUNCH_CHECK();
     const size_t rs = (size_t)E + 4 * T;
     const float *rows = p.rows;
-    // d W_f = d film^T s ; d W_2 = d v2^T a1 ; d W_1 = d v1^T sinus.  Over many rows these are plain fp32 GEMMs with the
-    // rows as the contraction index (library, as the recurrent weight gradients); a thread per weight element walking the
-    // rows is enough for the few rows of the reference's batch.
+    // d W_f = d film^T s ; d W_2 = d v2^T a1 ; d W_1 = d v1^T sinus: sums over the rows of outer products
     auto outer = [&](const float *left, size_t ls, const float *right, float *dw, int R, int K) -> int {
-        if (n_t >= TD_OUTER_LIB_MIN_ROWS) return td_outer_sum_lib(left, ls, right, rs, dw, R, K, n_t, stream);
-        hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(R * K, 256)), dim3(256), 0, stream, left, ls, right, rs, dw, R, K, n_t);
+        const int tiles = td_cdiv(R, TD_OS_TILE) * td_cdiv(K, TD_OS_TILE);
+        int nz = 1;
+        while (tiles * nz < 512 && n_t / (2 * nz) >= 128) nz *= 2;
+        hipLaunchKernelGGL(td_outer_sum_kernel, dim3(td_cdiv(R, TD_OS_TILE), td_cdiv(K, TD_OS_TILE), nz), dim3(256), 0, stream, left, ls,
+                           right, rs, dw, R, K, n_t);
         TD_LAUNCH_CHECK();
         return TD_OK;
     };

@@ -28,27 +28,14 @@ struct TdHeadFuseRun;   // rnn.hip: the sampler's fused head, not used in traini
 int td_rnn_run_layers_ex(const td_rnn_config *cfg, const void *packed, const float *x, int batch, int L, char *x0,
                          char *const *acts, float *const *saves, float *state, hipStream_t stream, const TdHeadFuseRun *fuse,
                          int l_first, int l_end);
-// gemm_lib.cpp (rocBLAS)
-int td_dw_gemm_lib(const void *A, size_t lda, const void *B, size_t ldb, float *C, int ldc, int M, int N, int K,
-                   int nsplit, float *partial, hipStream_t stream);
 int td_rnn_head(const td_rnn_config *cfg, const float *const *misc, const char *act, const float *film, int film_rows,
                 const int32_t *film_row, int batch, int L, float *y, hipStream_t stream, float *film_frags);
 size_t td_head_film_frag_bytes(const TdRnnGeom &g, int batch);
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// split-K of the library weight-gradient GEMMs: chunks of at least TD_DW_SPLIT_MIN_K columns, partial results within
-// TD_DW_PARTIAL_BYTES, until (256 x 256 tiles) x chunks reaches the CU count
-#define TD_DW_SPLIT_MIN_K 8192
+// split-K partial results of the weight-gradient GEMMs (td_dw_gemm) live in the training workspace
 #define TD_DW_PARTIAL_BYTES ((size_t)64 << 20)
-static int td_dw_nsplit(int M, int N, int K) {
-    const int tiles = td_cdiv(M, 256) * td_cdiv(N, 256);
-    int ns = 1;
-    while (ns < 64 && tiles * ns < 256 && K % (16 * ns) == 0 && K / (2 * ns) >= TD_DW_SPLIT_MIN_K &&
-           (size_t)M * N * sizeof(float) * (2 * ns) <= TD_DW_PARTIAL_BYTES)
-        ns *= 2;
-    return ns;
-}
 
 // ---------------------------------------------------------------------------------------------
 // inter-layer dropout (nn.LSTM / nn.GRU `dropout=`, blocks.py:268-270: every layer's output but the last one's is
@@ -164,7 +151,7 @@ static TdTrainLayout td_train_layout(const td_rnn_config *cfg, const TdRnnGeom &
     t.chan = take((size_t)L * t.nbb * (cfg->c_out + 1) * 32 * sizeof(float));   // head backward: g * rstd per channel, mu
     t.g1 = take((size_t)batch * cfg->c_out * sizeof(float));
     t.inbox = take(td_bptt_cluster_inbox_bytes(g, t.nbb));   // the cluster BPTT sweep's partial-sum exchange
-    t.dwpart = take(t.cols >= 2 * TD_DW_SPLIT_MIN_K ? TD_DW_PARTIAL_BYTES : 0);   // split-K partial results of the weight-gradient GEMMs
+    t.dwpart = take(t.cols >= 4 * 512 ? TD_DW_PARTIAL_BYTES : 0);   // split-K partial results of the weight-gradient GEMMs
     t.filmfr = take(td_head_film_frag_bytes(g, batch));   // per-sequence FiLM in fragment order (head forward / backward)
     // the MFMA head backward reads the forward's output and two per-sequence tables (td_head_bwd_dh_mfma_kernel)
     t.ysave = take(td_head_film_frag_bytes(g, batch) ? (size_t)batch * cfg->c_out * L * sizeof(float) : 0);
@@ -1231,70 +1218,176 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight-gradient GEMM: C[m][col(n)] += sum_k A[m][k] B[n][k]   (bf16 operands, fp32 atomics, split K)
+// weight-gradient GEMM: C[m][col(n)] += sum_k A[m][k] B[n][k]   (bf16 operands with k contiguous, fp32 accumulation)
+//
+// d W = d a . [x ; h]^T over all L * batch columns: M x N of a few hundred to a few thousand, K in the tens to hundreds
+// of thousands.  A workgroup (4 waves, 2 x 2) owns a 256 x 256 tile of C and one chunk of K (split K: with 4 x 2 tiles
+// only the chunks fill the chip); a stage = 64 columns of both operands, brought in by 16-byte loads of whole 128-byte row
+// segments, parked in registers while the previous stage is multiplied, and written to one of two LDS buffers whose rows
+// are padded to 144 bytes (the 32 rows a fragment read touches then fall into 16 distinct bank quads).  Both operands
+// have k contiguous, which is exactly the lane layout of v_mfma_f32_32x32x16_bf16's A and B fragments (8 k values per
+// lane), so a fragment is one ds_read_b128.  A chunk's tile goes to its own slab of `partial` and td_dw_reduce_kernel
+// adds the slabs in order: the sums do not depend on which workgroup finishes first (no atomics).
 // ---------------------------------------------------------------------------------------------
 struct TdDwParams {
     const __bf16 *A, *B;     // row-major, k contiguous
     float *C;
     size_t lda, ldb;
-    int ldc, M, N, K;        // M valid rows of A (rows beyond are zero-padded to a multiple of 32), N rows of B (multiple of 32)
+    int ldc, M, N, K;        // M valid rows of A, N rows of B (a multiple of 32)
     int hp, hv;              // column map: n -> (n / hp) * hv + n % hp, valid when n % hp < hv
-    int kchunk;
+    int kc, nsplit;          // columns per chunk (a multiple of TD_DW_BK), chunks
+    float *partial;          // nsplit > 1: [chunk][M][N] fp32
 };
 
-__global__ __launch_bounds__(256) void td_dw_gemm_kernel(TdDwParams p) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hf = lane >> 5;
-    const int mt = blockIdx.x, nt = blockIdx.y;
-    const int chunk = blockIdx.z * 4 + wave;
-    const int k0 = chunk * p.kchunk;
-    if (k0 >= p.K) return;
-    const int k1 = min(p.K, k0 + p.kchunk);
-    const __bf16 *ap = p.A + (size_t)(mt * 32 + r) * p.lda + 8 * hf;
-    const __bf16 *bp = p.B + (size_t)(nt * 32 + r) * p.ldb + 8 * hf;
-    f32x16 acc;
+#define TD_DW_BK 64
+#define TD_DW_ROWB 144
+
+// WM x WN: 32 x 32 MFMA tiles per wave; the four waves sit 2 x 2, so the workgroup's tile is (64 WM) x (64 WN)
+// EDGE: M, N or the chunk length are not multiples of the tile: loads and stores are predicated
+template <int WM, int WN, bool EDGE>
+__global__ __launch_bounds__(256, 1) void td_dw_gemm_kernel(TdDwParams p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, BK = TD_DW_BK, ROWB = TD_DW_ROWB;
+    constexpr int NLA = BM / 32, NLB = BN / 32;      // 16-byte pieces per thread and stage: rows row0 + 32 i
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+    const int k0 = split * p.kc, k1 = min(p.K, k0 + p.kc);
+    const int c = tid & 7, row0 = tid >> 3;
+    const __bf16 *ag = p.A + (size_t)(m0 + row0) * p.lda + c * 8, *bg = p.B + (size_t)(n0 + row0) * p.ldb + c * 8;
+    const size_t astep = (size_t)32 * p.lda, bstep = (size_t)32 * p.ldb;
+    bf16x8 va[NLA], vb[NLB];
+    auto gload = [&](int k) {
+        if constexpr (EDGE) {
+            const bool inside = k + c * 8 < k1;      // K is a multiple of 8: a piece is wholly inside or outside
+            const bf16x8 zero = {};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-    for (int k = k0; k < k1; k += 16)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(ap + k), *(const bf16x8 *)(bp + k), acc, 0, 0, 0);
-    const int n = nt * 32 + r;   // accumulator column
-    if (n % p.hp < p.hv) {
-        const int col = (n / p.hp) * p.hv + n % p.hp;
+            for (int i = 0; i < NLA; ++i) va[i] = (inside && m0 + row0 + 32 * i < p.M) ? *(const bf16x8 *)(ag + i * astep + k) : zero;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-            if (m < p.M) atomicAdd(&p.C[(size_t)m * p.ldc + col], acc[i]);
+            for (int i = 0; i < NLB; ++i) vb[i] = (inside && n0 + row0 + 32 * i < p.N) ? *(const bf16x8 *)(bg + i * bstep + k) : zero;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) va[i] = *(const bf16x8 *)(ag + i * astep + k);
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) vb[i] = *(const bf16x8 *)(bg + i * bstep + k);
         }
+    };
+    auto lstore = [&](int buf) {
+        char *base = lds + buf * (BM + BN) * ROWB + c * 16;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) *(bf16x8 *)(base + (row0 + 32 * i) * ROWB) = va[i];
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) *(bf16x8 *)(base + (BM + row0 + 32 * i) * ROWB) = vb[i];
+    };
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    if (k0 < k1) {
+        gload(k0);
+        lstore(0);
     }
+    __syncthreads();
+    int buf = 0;
+    for (int k = k0; k < k1; k += BK) {
+        const bool more = k + BK < k1;
+        if (more) gload(k + BK);
+        const char *ab = lds + buf * (BM + BN) * ROWB + (wm * 32 * WM + r) * ROWB + hf * 16;
+        const char *bb = lds + buf * (BM + BN) * ROWB + (BM + wn * 32 * WN + r) * ROWB + hf * 16;
+        // the fragments of k-step ks + 1 are read while k-step ks is multiplied (left to itself the compiler reads a fragment,
+        // waits for it and issues the four matrix instructions that use it: 65 % of this kernel's rate)
+        bf16x8 fa[2][WM], fb[2][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) fa[0][i] = *(const bf16x8 *)(ab + i * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) fb[0][j] = *(const bf16x8 *)(bb + j * 32 * ROWB);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks + 1 < BK / 16) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) fa[(ks + 1) & 1][i] = *(const bf16x8 *)(ab + i * 32 * ROWB + (ks + 1) * 32);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) fb[(ks + 1) & 1][j] = *(const bf16x8 *)(bb + j * 32 * ROWB + (ks + 1) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();     // the other buffer is complete, and every wave is done with this one
+        buf ^= 1;
+    }
+    // accumulator element q of lane (r, hf): row (q & 3) + 8 (q >> 2) + 4 hf, column r of its 32 x 32 tile
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + (wn * WN + j) * 32 + r;
+            if (n >= p.N) continue;
+            if (p.nsplit > 1) {
+                float *dst = p.partial + (size_t)split * p.M * p.N + n;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
+                    if (m < p.M) dst[(size_t)m * p.N] = acc[i][j][q];
+                }
+            } else if (n % p.hp < p.hv) {
+                const int col = (n / p.hp) * p.hv + n % p.hp;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
+                    if (m < p.M) p.C[(size_t)m * p.ldc + col] += acc[i][j][q];     // this workgroup owns the tile
+                }
+            }
+        }
 }
 
-// The library GEMM where the shape allows (no column remap: hidden a multiple of 32, not the first layer's padded
-// channels; leading dimensions within rocBLAS's 32-bit range), the kernel above otherwise.  The choice depends on the
-// shape (and the explicit td_set_dw_gemm knob) only: a library failure is returned as an error.
-// C[m][n] += sum over the nsplit partial results (each M x N, packed)
-__global__ __launch_bounds__(256) void td_dw_reduce_kernel(const float *__restrict__ part, float *__restrict__ C, int M, int N, int ldc,
-                                                           int nsplit) {
-    const size_t total = (size_t)M * N;
+// C[m][col(n)] += sum over the chunks' slabs (each M x N, packed), in chunk order
+__global__ __launch_bounds__(256) void td_dw_reduce_kernel(TdDwParams p) {
+    const size_t total = (size_t)p.M * p.N;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i % p.N);
+        if (n % p.hp >= p.hv) continue;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + i];
-        C[(i / N) * ldc + i % N] += s;
+        for (int k = 0; k < p.nsplit; ++k) s += p.partial[(size_t)k * total + i];
+        p.C[(i / p.N) * p.ldc + (n / p.hp) * p.hv + n % p.hp] += s;
     }
 }
 
-int td_dw_gemm_mode(void);   // api.cpp
-static int td_dw_gemm(const TdDwParams &q, int nu, float *partial, hipStream_t stream) {
-    if (q.hp == q.hv && td_dw_gemm_mode() != TD_DW_GEMM_KERNEL && q.lda <= 0x7fffffff && q.ldb <= 0x7fffffff) {
-        const int ns = partial ? td_dw_nsplit(q.M, q.N, q.K) : 1;
-        int rc = td_dw_gemm_lib(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, ns, partial, stream);
-        if (rc != TD_OK || ns == 1) return rc;
-        const size_t total = (size_t)q.M * q.N;
-        hipLaunchKernelGGL(td_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, q.C, q.M, q.N, q.ldc, ns);
-        TD_LAUNCH_CHECK();
-        return TD_OK;
-    }
-    hipLaunchKernelGGL(td_dw_gemm_kernel, dim3(nu, q.N / 32, td_cdiv(td_cdiv(q.K, q.kchunk), 4)), dim3(256), 0, stream, q);
+// Chunks of K: enough of them that tiles x chunks cover the chip, each at least TD_DW_MIN_KC columns, all slabs within the
+// workspace's TD_DW_PARTIAL_BYTES.  Tile: 256 x 256 (a wave 128 x 128: 8 fragment reads feed 16 matrix instructions);
+// 256 x 64 where B has few rows (the first layer's input channels).
+#define TD_DW_MIN_KC 512
+static int td_dw_gemm(TdDwParams q, float *partial, hipStream_t stream) {
+    const bool narrow = q.N <= 64;
+    const int bm = 256, bn = narrow ? 64 : 256;
+    const int tm = td_cdiv(q.M, bm), tn = td_cdiv(q.N, bn);
+    int ns = 1;
+    while (partial && ns < 128 && tm * tn * ns < 256 && q.K / (2 * ns) >= TD_DW_MIN_KC &&
+           (size_t)q.M * q.N * sizeof(float) * (2 * ns) <= TD_DW_PARTIAL_BYTES)
+        ns *= 2;
+    q.kc = TD_DW_BK * td_cdiv(td_cdiv(q.K, ns), TD_DW_BK);
+    q.nsplit = td_cdiv(q.K, q.kc);
+    q.partial = partial;
+    TD_REQUIRE(q.K % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0, "weight-gradient GEMM: K and the leading dimensions must be multiples of 8");
+    const bool edge = q.M % bm != 0 || q.N % bn != 0 || q.K % TD_DW_BK != 0;   // a short last chunk is whole stages still
+    const dim3 grid(tm, tn, q.nsplit);
+    if (narrow && edge) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 1, true>), grid, dim3(256), 0, stream, q);
+    else if (narrow) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 1, false>), grid, dim3(256), 0, stream, q);
+    else if (edge) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 4, true>), grid, dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL((td_dw_gemm_kernel<4, 4, false>), grid, dim3(256), 0, stream, q);
     TD_LAUNCH_CHECK();
+    if (q.nsplit > 1) {
+        const size_t total = (size_t)q.M * q.N;
+        hipLaunchKernelGGL(td_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, q);
+        TD_LAUNCH_CHECK();
+    }
     return TD_OK;
 }
 
@@ -1329,7 +1422,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
     const TdTrainLayout t = td_train_layout(cfg, g, batch, L);
     const TdPackTGeom tg = td_packT_geom(cfg, g);
     int rc = TD_OK;
-    float *dwpart = t.cols >= 2 * TD_DW_SPLIT_MIN_K ? (float *)(ws + t.dwpart) : nullptr;
+    float *dwpart = t.cols >= 4 * 512 ? (float *)(ws + t.dwpart) : nullptr;
     // ---- layers, top down ------------------------------------------------------------------------
     const int KT = D * g.kh;
     for (int l = N - 1; l >= 0; --l) {
@@ -1406,14 +1499,13 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
             for (int gate = 0; gate < G; gate += GM) {
                 const int slab_x = gate, slab_h = (cfg->gru && gate == 2) ? 3 : gate;
                 TdDwParams q;
-                q.kchunk = 2048;
                 // W_ih
                 q.A = dapl + (size_t)slab_x * t.dapl_slab_elems; q.lda = t.cols;
                 q.B = (const __bf16 *)(ws + t.plainx[l]); q.ldb = t.cols;     // this layer's input (the dropped copy, with dropout)
                 q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = GM * H; q.K = (int)t.cols;
                 if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
                 else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
-                rc = td_dw_gemm(q, GM * g.nu, dwpart, stream);
+                rc = td_dw_gemm(q, dwpart, stream);
                 if (rc != TD_OK) return rc;
                 // W_hh: h_{t-1} is this direction's own output one step earlier in its processing order
                 if (L > 1) {
@@ -1423,7 +1515,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                     q.B = d == 0 ? hpl : hpl + t.Bp;
                     q.C = gw[1] + (size_t)gate * H * H; q.ldc = H; q.K = (int)(t.cols - t.Bp);
                     q.N = g.hpad; q.hp = g.hpad; q.hv = H;
-                    rc = td_dw_gemm(q, GM * g.nu, dwpart, stream);
+                    rc = td_dw_gemm(q, dwpart, stream);
                     if (rc != TD_OK) return rc;
                 }
                 // biases (hidden sizes up to 256: folded into the sweep)

@@ -114,8 +114,12 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
 
     // One graph launch carries several steps: a launch costs the GPU an idle gap of the order of a millisecond
     // (measured: 36.0 ms per step with one step per launch against 35.0 ms of kernel time).
-    const int steps_per_graph = T >= TD_STEPS_PER_GRAPH ? TD_STEPS_PER_GRAPH : 1;
-    if (use_graph) {
+    // A captured launch of a cluster kernel (rnn_cluster.hip) carries its hand-off tags' launch epoch baked in, and stale
+    // tags are told apart only because the launch before it on the same exchange buffer had another epoch: a graph
+    // therefore holds at least two denoiser passes (one layer = one cluster launch per pass), and a one-step chain is
+    // not captured at all.
+    const int steps_per_graph = T >= TD_STEPS_PER_GRAPH ? TD_STEPS_PER_GRAPH : 2;
+    if (use_graph && T >= 2) {
         // The instantiated step graph is kept for the next call with identical arguments; a stale one
         // is released only after the stream it ran on has drained.
         TdChainKey key;

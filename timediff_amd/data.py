@@ -96,7 +96,9 @@ class TimeSeriesDataset(Dataset):
             if keep:
                 y[:, keep, :] = x[:, keep, :]
             rest = [c for c in range(C) if c not in keep]
-            assert bool(((y[:, rest] >= 0) & (y[:, rest] <= 1)).all()), "failed to normalize data"
+            # as normalize_data (utils.py:143 of the reference): NaNs -- a constant channel gives 0 / 0 -- are left out of the check
+            inside = y[:, rest][~torch.isnan(y[:, rest])]
+            assert bool(((inside >= 0) & (inside <= 1)).all()), "failed to normalize data"
             stage[i:i + self.CHUNK] = y
         torch.save(stage, files["data"])
         del stage
