@@ -226,6 +226,8 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
     fwd_flops = seqs * D * 2.0 * L * 4 * H * (D * H + H)     # W_hh h + W_ih x, one layer, both directions
     bptt_flops = seqs * D * 2.0 * L * 4 * H * H               # W_hh^T d a (d x and d W are separate GEMM launches)
     kernels = {}
+    graphed = bool(et._graphs) and all("graph" in e for e in et._graphs.values())
+    et.graph_steps = False      # the probes below bracket kernels with events launch by launch; a replayed graph has none
     for kind, name, fl in ((_lib.PROFILE_LAYER_SAVE, "saving forward, layers above the first", fwd_flops),
                            (_lib.PROFILE_BPTT_SWEEP, "BPTT sweep, layers above the first", bptt_flops)):
         _lib.check(lib.td_profile_enable(kind))
@@ -248,7 +250,8 @@ def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
                 config=dict(workload=f"ETDiff eICU-shaped training step: global batch {batch}, grad-accum {ga}, L={L}, "
                                      f"3-layer bidirectional LSTM H={H}, T={T}, Adam + clip + EMA",
                             batch=batch, gradient_accumulate_every=ga,
-                            accumulation="micro-batches concatenated into one launch" if fuse and ga > 1 else "loop"),
+                            accumulation="micro-batches concatenated into one launch" if fuse and ga > 1 else "loop",
+                            launch="one captured graph per optimizer step" if graphed else "kernel by kernel"),
                 sequences_per_s=steps * batch * ga / el, final_loss=float(loss))
 
 

@@ -191,6 +191,8 @@ typedef struct td_rng {
     uint64_t seed;
     uint32_t patient0;
     uint32_t tag;
+    const uint64_t *seed_dev;   /* NULL, or a device word ADDED to seed when the kernel runs: a launch captured in a hipGraph
+                                   draws fresh noise on every replay (the caller rewrites the word between replays) */
 } td_rng;
 
 /* mixed_diffusion.py:403-409 + :375-387: normalize_numericals, gauss_q_sample (:240-248),
@@ -266,6 +268,19 @@ TD_API int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_config *
  * No counterpart in the reference. */
 TD_API int td_sample_chain_release(void);
 
+/* What changes from one optimizer step to the next, as a record in DEVICE memory: td_clip_adam_ema_rec reads it when the
+ * kernel runs, so a whole training step captured in a hipGraph is replayed with fresh values (the caller
+ * rewrites it with td_step_record_set before each replay; `seed` is for td_rng.seed_dev).  No counterpart
+ * in the reference. */
+typedef struct td_step_record {
+    uint64_t seed;
+    float step_size;      /* lr / (1 - beta1^step) */
+    float inv_sqrt_bc2;   /* 1 / sqrt(1 - beta2^step) */
+    float ema_decay;
+    int32_t ema_mode;
+    uint64_t reserved;
+} td_step_record;
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer step of ETDiff.train (models/ETDiff/et_diff.py:239 clip_grad_norm_(1.0), :75/:247
  * torch.optim.Adam(lr, betas), :254 EMA update) over FLAT fp32 buffers of all parameters.
@@ -278,6 +293,14 @@ TD_API int td_grad_norm(const float *grad, size_t n, float *norm, void *workspac
 TD_API int td_clip_adam_ema(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, size_t n,
                      const float *norm, float max_norm, float lr, float beta1, float beta2, float eps, int32_t step,
                      int32_t ema_mode, float ema_decay, void *stream);
+/* The same pass with step size, bias correction and EMA mode / decay read from a td_step_record in device memory when the
+ * kernel runs (hipGraph replay); td_step_record_set computes the record exactly as td_clip_adam_ema computes its own
+ * values from (lr, betas, step) and writes it to device memory by a one-thread kernel (stream-ordered, no host buffer). */
+TD_API int td_step_record_set(td_step_record *record_dev, uint64_t seed, float lr, float beta1, float beta2, int32_t step,
+                       int32_t ema_mode, float ema_decay, void *stream);
+TD_API int td_clip_adam_ema_rec(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, size_t n,
+                         const float *norm, float max_norm, float beta1, float beta2, float eps,
+                         const td_step_record *record, void *stream);
 
 /* ---- TSTR classifier: the nearest downstream consumer of the same recurrent kernels --------------------------------
  * evaluate/nn_classifier.py:89-127 (class RNN: bidirectional nn.LSTM / nn.GRU over (B, C, L), final hidden state of each

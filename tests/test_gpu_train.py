@@ -176,3 +176,119 @@ def test_checkpoint_written_beside_training(dev, tmp_path):
     et.save_weights(block=False)
     with pytest.raises(Exception):
         et.wait_for_checkpoint()
+
+
+def _static_draws(g, dev, per_call):
+    """Device tensors the patched forward reads its (t, noise, uniforms) from: a captured step bakes addresses, not values."""
+    return [{k: torch.empty((per_call * g[k].shape[1],) + g[k].shape[2:], dtype=torch.from_numpy(g[k]).dtype, device=dev)
+             for k in ("t", "noise", "uniforms")} for _ in range(2)]
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_train_steps_against_reference_graphed(fuse, dev, tmp_path):
+    """The same two golden optimizer steps with the whole step captured in a graph at the first call (no warm-up) and
+    replayed: the draws are fed through static device tensors that are rewritten between replays."""
+    g = load_golden("train_steps_eicu")
+    L, H, N, T, B, ga = [int(v) for v in g["cfg"]]
+    lr = float(g["lr"])
+    et = _build(g, dev, ga, lr, tmp_path, T, L, H, N, fuse)
+    assert et._graph_eligible()
+    et.graph_warmup = 0
+    et.dl = iter([torch.from_numpy(b.copy()) for b in g["data"]])
+    per_call = ga if fuse else 1
+    calls = ga // per_call                      # forward calls per optimizer step
+    static = _static_draws(g, dev, per_call)
+    inner, count = et.model.forward, [0]
+
+    def forward(sample):
+        j = count[0] % calls
+        count[0] += 1
+        return inner(sample, **static[j])
+    et.model.forward = forward
+    for step in range(2):
+        for j in range(calls):
+            i0 = (step * calls + j) * per_call
+            for k in ("t", "noise", "uniforms"):
+                static[j][k].copy_(torch.cat([torch.from_numpy(g[k][i0 + m]) for m in range(per_call)]))
+        loss = et.train_step().item()
+        assert count[0] == calls, "the step must have been captured once and replayed"
+        np.testing.assert_allclose(loss, g["total_loss"][step], rtol=2e-2)
+        np.testing.assert_allclose(et._norm.item(), g["grad_norm"][step], rtol=5e-2)
+        sd = {k: v.detach().cpu().numpy() for k, v in et.model.state_dict().items()}
+        for k, ref in sub(g, f"step{step}.").items():
+            err = np.abs(sd[k] - ref)
+            assert err.max() <= 2.2 * lr * (step + 1), (k, err.max())
+            assert (err > 0.3 * lr).mean() < 0.08, (k, (err > 0.3 * lr).mean())
+    assert et.step == 2 and et.opt_step == 2 and len(et._graphs) == 1
+    assert float(et.flat_grad.abs().max()) == 0.0
+    for p, q in zip(et.model.parameters(), et.ema.ema_model.parameters()):
+        assert torch.equal(p, q) and p.data_ptr() != q.data_ptr()
+    # the denoiser's weight cache was marked stale: the EMA model samples from the trained weights
+    out = et.ema.ema_model.sample(batch_size=3)
+    assert out.shape == (3, 9, L) and torch.isfinite(out).all()
+
+
+def test_graphed_steps_equal_launch_by_launch(dev, tmp_path):
+    """Six optimizer steps, noise from the in-kernel generator: a trainer that replays its captured step (seed read from the
+    device record) and one that launches kernel by kernel (seed as a kernel argument) draw the same seeds from torch's CPU
+    generator and must end at the same weights, Adam moments and EMA (ema_update_every = 1, lerp from step 1 on)."""
+    g = load_golden("train_steps_eicu")
+    L, H, N, T, B, ga = [int(v) for v in g["cfg"]]
+    lr = 1e-3
+    data = torch.from_numpy(g["data"].reshape(-1, *g["data"].shape[2:]).copy())
+    rows = torch.randint(0, data.shape[0], (6, 2 * B), generator=torch.Generator().manual_seed(5))
+    ts = torch.randint(0, T, (6, 2 * B), generator=torch.Generator().manual_seed(6))
+    ends = []
+    for graphed in (False, True):
+        et = _build(g, dev, ga, lr, tmp_path, T, L, H, N, True)
+        et.graph_steps, et.graph_warmup = graphed, 1
+        et.ema.update_after_step = 0        # decay > 0 from the second update on: the lerp branch of the record runs
+        et.dl = iter([data[r].clone() for r in rows.reshape(12, B)])
+        t_dev = torch.empty(2 * B, dtype=torch.int64, device=dev)
+        inner = et.model.forward
+        et.model.forward = lambda sample, inner=inner, t_dev=t_dev: inner(sample, t=t_dev)
+        torch.manual_seed(77)
+        losses = []
+        for step in range(6):
+            t_dev.copy_(ts[step])
+            losses.append(et.train_step().item())
+        assert (len(et._graphs) == 1 and "graph" in next(iter(et._graphs.values()))) == graphed
+        ends.append((losses, et.flat_param.clone(), et.exp_avg.clone(), et.exp_avg_sq.clone(), et.flat_ema.clone(), et.opt_step))
+    (la, pa, ma, va, ea, sa), (lb, pb, mb, vb, eb, sb) = ends
+    assert sa == sb == 6
+    np.testing.assert_allclose(la, lb, rtol=1e-4)
+    # bias gradients are summed with atomics (order varies in the last bits): Adam's update may differ where g ~ 0
+    for a, b, name in ((pa, pb, "param"), (ea, eb, "ema")):
+        err = (a - b).abs()
+        assert float(err.max()) <= 2.2 * lr * 6, name
+        assert float((err > 0.05 * lr).float().mean()) < 0.01, (name, float((err > 0.05 * lr).float().mean()))
+    assert not torch.equal(pa, ea)
+    torch.testing.assert_close(ma, mb, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(va, vb, rtol=1e-3, atol=1e-9)
+
+
+def test_step_record_optimizer_equals_host_arguments(dev):
+    """td_clip_adam_ema_rec (step size, bias correction, EMA mode / decay from a td_step_record in device memory) is
+    bit-identical to td_clip_adam_ema given the same values as arguments, for every EMA mode."""
+    import ctypes as C
+    from timediff_amd import _lib
+    from timediff_amd._lib import check, lib, ptr
+    n = 100003
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    base = [torch.randn(n, generator=gen) for _ in range(5)]
+    base[3] = base[3].abs() * 1e-4
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rec = torch.zeros(C.sizeof(_lib.StepRecord), dtype=torch.uint8, device=dev)
+    for mode, step in ((0, 1), (1, 2), (2, 977)):
+        a = [t.clone().to(dev) for t in base]
+        b = [t.clone().to(dev) for t in base]
+        norm = torch.full((1,), 3.0, device=dev)
+        check(lib().td_clip_adam_ema(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), n, ptr(norm), 1.0, 8e-5, 0.9, 0.99,
+                                     1e-8, step, mode, 0.9931, st))
+        check(lib().td_step_record_set(ptr(rec), 12345, 8e-5, 0.9, 0.99, step, mode, 0.9931, st))
+        check(lib().td_clip_adam_ema_rec(ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(b[3]), ptr(b[4]), n, ptr(norm), 1.0, 0.9, 0.99, 1e-8,
+                                         ptr(rec), st))
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        host = _lib.StepRecord.from_buffer_copy(rec.cpu().numpy().tobytes())
+        assert host.seed == 12345 and host.ema_mode == mode

@@ -37,7 +37,13 @@ class DiffusionConfig(C.Structure):
 
 
 class Rng(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("patient0", C.c_uint32), ("tag", C.c_uint32)]
+    _fields_ = [("seed", C.c_uint64), ("patient0", C.c_uint32), ("tag", C.c_uint32), ("seed_dev", C.c_void_p)]
+
+
+class StepRecord(C.Structure):
+    """td_step_record: what changes from one optimizer step to the next (read on the device by a captured training step)."""
+    _fields_ = [("seed", C.c_uint64), ("step_size", C.c_float), ("inv_sqrt_bc2", C.c_float), ("ema_decay", C.c_float),
+                ("ema_mode", C.c_int32), ("reserved", C.c_uint64)]
 
 
 class TimediffError(RuntimeError):
@@ -89,6 +95,8 @@ _SIGS = {
     "td_grad_norm": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "td_clip_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, _I, _I, C.c_float, _P]),
+    "td_step_record_set": (C.c_int, [_P, C.c_uint64, C.c_float, C.c_float, C.c_float, _I, _I, C.c_float, _P]),
+    "td_clip_adam_ema_rec": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "td_set_layer_kernel": (C.c_int, [_I]),
     "td_rnn_layer_kernel_choice": (C.c_int, [C.POINTER(RnnConfig), _I, _I]),
     "td_cls_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),

@@ -128,7 +128,7 @@ struct TdDraw {
     float nbuf[VEC][4], ubuf[VEC][TD_UNI_PER_BLOCK];
     int nblk, ublk;
     __device__ TdDraw(const float *n, const float *u, td_rng rng, int b, int l0_, int n_num, int sumk, int L_, uint32_t tag_)
-        : noise(n), uniforms(u), seed(rng.seed), patient(rng.patient0 + (uint32_t)b), l0((uint32_t)l0_), tag(tag_),
+        : noise(n), uniforms(u), seed(rng.seed + (rng.seed_dev ? *rng.seed_dev : 0ull)), patient(rng.patient0 + (uint32_t)b), l0((uint32_t)l0_), tag(tag_),
           nbase(((size_t)b * n_num) * L_ + l0_), ubase(((size_t)b * sumk) * L_ + l0_), L(L_), nblk(-1), ublk(-1) {}
     __device__ TdVec<VEC> normal(int ch) {
         if (noise) return td_ldf<VEC>(noise + nbase + (size_t)ch * L);
@@ -458,7 +458,7 @@ extern "C" int td_reverse_step_terms(const td_diffusion_config *cfg, int32_t bat
     TdRevParams p;
     p.c = *cfg; p.B = batch; p.sumk = td_sum_k(cfg); p.t_host = t; p.mo = model_out; p.z = (float *)z; p.idx = (uint8_t *)idx;
     p.t_dev = nullptr; p.noise = nullptr; p.uniforms = nullptr; p.noise_stride = 0; p.uni_stride = 0;
-    p.rng.seed = 0; p.rng.patient0 = 0; p.rng.tag = 0;
+    p.rng.seed = 0; p.rng.patient0 = 0; p.rng.tag = 0; p.rng.seed_dev = nullptr;
     p.x0_out = x0; p.mean_out = mean; p.log_theta_out = log_theta;
     return td_launch_reverse<true>(p, (hipStream_t)stream);
 }

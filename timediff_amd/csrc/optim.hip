@@ -50,11 +50,16 @@ struct TdAdamParams {
     size_t n;
     float max_norm, step_size, inv_sqrt_bc2, beta1, beta2, eps, ema_decay;
     int ema_mode;  // 0: leave the EMA alone, 1: copy the new weights, 2: ema = decay * ema + (1 - decay) * w
+    const td_step_record *rec;   // non-NULL: step_size, inv_sqrt_bc2, ema_decay and ema_mode come from this device record
 };
 
 __global__ __launch_bounds__(256) void td_clip_adam_ema_kernel(TdAdamParams a) {
     // clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
     const float coef = a.max_norm > 0.f ? fminf(1.0f, a.max_norm / (a.norm[0] + 1e-6f)) : 1.0f;
+    if (a.rec) {
+        a.step_size = a.rec->step_size; a.inv_sqrt_bc2 = a.rec->inv_sqrt_bc2;
+        a.ema_decay = a.rec->ema_decay; a.ema_mode = a.rec->ema_mode;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
         const float g = a.g[i] * coef;
         const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
@@ -79,6 +84,41 @@ extern "C" int td_clip_adam_ema(float *param, const float *grad, float *exp_avg,
     a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.ema_decay = ema_decay; a.ema_mode = ema_mode;
     a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    a.rec = nullptr;
+    size_t b = (n + 255) / 256;
+    const int blocks = (int)(b > 4096 ? 4096 : b);
+    hipLaunchKernelGGL(td_clip_adam_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+__global__ void td_step_record_kernel(td_step_record *dst, td_step_record v) { *dst = v; }
+
+extern "C" int td_step_record_set(td_step_record *record_dev, uint64_t seed, float lr, float beta1, float beta2, int32_t step,
+                                  int32_t ema_mode, float ema_decay, void *stream) {
+    TD_REQUIRE(record_dev && step >= 1, "bad argument");
+    td_step_record r;
+    r.seed = seed;
+    r.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    r.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    r.ema_decay = ema_decay;
+    r.ema_mode = ema_mode;
+    r.reserved = 0;
+    hipLaunchKernelGGL(td_step_record_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, record_dev, r);   // the values travel as kernel arguments
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+extern "C" int td_clip_adam_ema_rec(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, size_t n,
+                                    const float *norm, float max_norm, float beta1, float beta2, float eps,
+                                    const td_step_record *record, void *stream) {
+    TD_REQUIRE(param && grad && exp_avg && exp_avg_sq && ema && record && n > 0, "bad argument");
+    TD_REQUIRE(max_norm <= 0.f || norm, "norm pointer required when clipping");
+    TdAdamParams a;
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.ema = ema; a.norm = norm; a.n = n;
+    a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.ema_decay = 0.f; a.ema_mode = 0; a.step_size = 0.f; a.inv_sqrt_bc2 = 1.f;
+    a.rec = record;
     size_t b = (n + 255) / 256;
     const int blocks = (int)(b > 4096 ? 4096 : b);
     hipLaunchKernelGGL(td_clip_adam_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

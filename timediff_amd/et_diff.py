@@ -209,6 +209,15 @@ class ETDiff(nn.Module):
             self._layer_slices = layer_slices(names, [p.numel() for p in self.params], self._n_layers)
         self.opt_step = 0
         self.step = 0
+        # One process, one fused batch, no dropout: the whole optimizer step (q_sample ... Adam/EMA, about sixty small
+        # launches) is captured once per (batch, L) signature and replayed as ONE graph launch; what changes from step to
+        # step (the noise seed, Adam's bias corrections, what the EMA does) is read by the kernels from a device record
+        # (td_step_record) that is rewritten before each replay.  TIMEDIFF_TRAIN_GRAPH=0 keeps the launch-by-launch path;
+        # TIMEDIFF_TRAIN_GRAPH_WARMUP = optimizer steps run launch by launch before a signature is captured.
+        self.graph_steps = os.environ.get("TIMEDIFF_TRAIN_GRAPH", "1") != "0"
+        self.graph_warmup = int(os.environ.get("TIMEDIFF_TRAIN_GRAPH_WARMUP", "2"))
+        self._graphs = {}
+        self._rec = torch.zeros(C.sizeof(_lib.StepRecord), dtype=torch.uint8, device=self._device)
 
     def _shared_int(self, value):
         """rank 0's `value` on every rank."""
@@ -418,13 +427,84 @@ class ETDiff(nn.Module):
             if hasattr(mod, "_film_version"):
                 mod._film_version = None
 
+    # -- the optimizer step as one graph launch ------------------------------------------------------
+    def _graph_eligible(self):
+        """A captured step holds no host decision: one rank (no all-reduce callbacks), no inter-layer dropout (its seed is a
+        host draw), the denoiser on this library's kernels.  Two recurrent layers at least: a captured cluster-kernel launch
+        carries its hand-off epoch baked in, and stale tags are told apart only because the launch before it on the same
+        exchange buffer had another epoch (csrc/sampler.hip says the same of the sampler's graph)."""
+        den = getattr(self.model, "model", None)
+        return (self.graph_steps and not self._dp and self._sink is not None and self._n_layers >= 2
+                and not (den.training and den.dropout > 0))
+
+    def _capture_step(self, batches):
+        den = self.model.model
+        xs = [torch.empty(b.shape, dtype=b.dtype, device=self.device) for b in batches]
+        for x, b in zip(xs, batches):
+            x.copy_(b, non_blocking=True)
+        # what the kernels keep between calls is allocated here, outside the graph's memory pool, and the entry holds on
+        # to it: a later, larger eager batch may replace the denoiser's workspace, this graph keeps using its own
+        k = den.kernels()
+        keep = (k, k.packed) + tuple(k.reserve_train(max(b.shape[0] for b in batches), batches[0].shape[2]))
+        self.model.kernels()
+        den._kernels_version = None       # the weight repack is part of every replay
+        n, ga = self.flat_param.numel(), len(batches)
+        graph = torch.cuda.CUDAGraph()
+        self.model._seed_dev = self._rec
+        try:
+            with torch.cuda.graph(graph):
+                total = torch.zeros((), dtype=torch.float32, device=self.device)
+                for i, x in enumerate(xs):
+                    self.model._seed_base = i       # micro-batch i draws with seed = record's seed + i
+                    loss = self.model(x) / ga
+                    total += loss.detach()
+                    loss.backward()
+                check(lib().td_grad_norm(ptr(self.flat_grad), n, ptr(self._norm), ptr(self._norm_ws), _stream()))
+                check(lib().td_clip_adam_ema_rec(ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                                 ptr(self.flat_ema), n, ptr(self._norm), 1.0, self.betas[0], self.betas[1], self.eps,
+                                                 ptr(self._rec), _stream()))
+                self.flat_grad.zero_()
+        finally:
+            self.model._seed_dev = None
+            self.model._seed_base = 0
+        return {"graph": graph, "x": xs, "loss": total, "keep": keep}
+
+    def _train_step_graphed(self, batches):
+        """-> the step's loss, or None while this signature (the micro-batch shapes) is still in its launch-by-launch
+        warm-up."""
+        key = tuple((tuple(b.shape), b.dtype) for b in batches)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {"seen": 0}
+        if "graph" not in ent and ent["seen"] < self.graph_warmup:
+            ent["seen"] += 1
+            return None
+        self.opt_step += 1
+        mode, decay = self.ema.plan_update()
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # torch's CPU generator: torch.manual_seed repeats a run
+        check(lib().td_step_record_set(ptr(self._rec), seed, self.lr, self.betas[0], self.betas[1], self.opt_step, mode, decay,
+                                       _stream()))
+        if "graph" not in ent:
+            ent.update(self._capture_step(batches))     # capturing runs nothing: the first replay below is this step
+        else:
+            for x, b in zip(ent["x"], batches):
+                x.copy_(b, non_blocking=True)
+        ent["graph"].replay()
+        self._bump_versions()
+        self.step += 1
+        return ent["loss"].clone()
+
     def train_step(self):
         """gradient_accumulate_every micro-batches + one optimizer step; -> the step's loss (device scalar)."""
         ga = self.gradient_accumulate_every
-        total = torch.zeros((), dtype=torch.float32, device=self.device)
         batches = [next(self.dl) for _ in range(ga)]
         if self.fuse_accumulation and ga > 1 and all(b.shape[0] == batches[0].shape[0] for b in batches):
             batches, ga = [torch.cat(batches)], 1       # mean over the concatenation = sum of the micro-batch means / ga
+        if self._graph_eligible():
+            loss = self._train_step_graphed(batches)
+            if loss is not None:
+                return loss
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
         for i, data in enumerate(batches):
             if self._sink is not None:
                 overlap = self._dp and self._overlap and i == ga - 1

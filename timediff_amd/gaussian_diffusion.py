@@ -55,7 +55,9 @@ class GaussianDiffusion(nn.Module):
         sample = sample.to(dk.device)
         if t is None:
             t = torch.randint(0, self.num_timesteps, (b,), device=dk.device).long()
-        x_in, x0_idx, xt_idx, eps = dk.q_sample(sample, t, noise, None, seed=_fresh_seed(), tag=0x40000000)
+        seed_dev = getattr(self, "_seed_dev", None)      # set by ETDiff while it captures / replays a training step
+        x_in, x0_idx, xt_idx, eps = dk.q_sample(sample, t, noise, None, seed=getattr(self, "_seed_base", 0) if seed_dev is not None else _fresh_seed(),
+                                                tag=0x40000000, seed_dev=seed_dev)
         model_out = self.model(x_in, t, None)
         return _LossFn.apply(model_out, dk, eps, x0_idx, xt_idx, t, 0.0)
 

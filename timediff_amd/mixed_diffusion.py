@@ -94,6 +94,7 @@ class MixedDiffusion(nn.Module):
                 # create_samples (:173-179) sizes the result `channels - n_cat`
                 self.channels - n_cat, dev, auto_normalize=self.auto_normalize)
             self._sampler = None
+            self._num_idx_dev = torch.tensor(self.numerical_features_indices, dtype=torch.int64, device=dev)
         return self._kernels
 
     def __deepcopy__(self, memo):
@@ -113,10 +114,14 @@ class MixedDiffusion(nn.Module):
         sample = sample.to(dev)
         if t is None:
             t = torch.randint(0, self.num_timesteps, (b,), device=dev).long()
-        x_in, x0_idx, xt_idx, eps = dk.q_sample(sample, t, noise, uniforms, seed=_fresh_seed(), tag=0x40000000)
+        # a captured training step (ETDiff) reads the seed from device memory: a host draw would be baked into the graph
+        seed_dev = getattr(self, "_seed_dev", None)
+        x_in, x0_idx, xt_idx, eps = dk.q_sample(sample, t, noise, uniforms, seed=getattr(self, "_seed_base", 0) if seed_dev is not None else _fresh_seed(),
+                                                tag=0x40000000, seed_dev=seed_dev)
         # the reference normalises the caller's batch in place (normalize_numericals, :189-194)
         if self.auto_normalize:
-            sample[:, self.numerical_features_indices, :] = sample[:, self.numerical_features_indices, :] * 2 - 1
+            ch = self._num_idx_dev      # the channel list as a device tensor (a list index is a host-to-device copy per call)
+            sample[:, ch, :] = sample[:, ch, :] * 2 - 1
         model_out = self.model(x_in, t, None)
         return _LossFn.apply(model_out, dk, eps, x0_idx, xt_idx, t, float(self.loss_lambda))
 

@@ -130,15 +130,25 @@ class DenoiserKernels:
         check(lib().td_rnn_dropout_mask(C.byref(self.cfg), batch, seq_len, layer, ptr(m), _stream()))
         return m
 
+    def reserve_train(self, batch, seq_len):
+        """Allocates what forward_train / backward of this shape keep between calls (the training workspace, the transposed
+        weight cache): a caller that captures them in a graph does this first, outside the capture."""
+        need = lib().td_rnn_train_workspace_bytes(C.byref(self.cfg), batch, seq_len)
+        if need == 0:
+            raise _lib.TimediffError(lib().td_last_error().decode() or "bad training shape")
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = None
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self._packT is None:
+            self._packT = torch.empty(lib().td_rnn_packT_bytes(C.byref(self.cfg)), dtype=torch.uint8, device=self.device)
+        return self._train_ws, self._packT
+
     def forward_train(self, x, film):
         """Forward that keeps the activations for `backward` (one film row per batch element)."""
         x, film = _f32(x), _f32(film)
         B, _, L = x.shape
         assert film.shape == (B, 2 * self.cfg.dirs * self.cfg.hidden)
-        need = lib().td_rnn_train_workspace_bytes(C.byref(self.cfg), B, L)
-        if self._train_ws is None or self._train_ws.numel() < need:
-            self._train_ws = None
-            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.reserve_train(B, L)
         y = torch.empty(B, self.cfg.c_out, L, dtype=torch.float32, device=self.device)
         check(lib().td_rnn_forward_train(C.byref(self.cfg), ptr(self.packed), self._misc_tab, ptr(x), ptr(film), B, L,
                                          ptr(y), ptr(self._train_ws), _stream()))
@@ -154,8 +164,6 @@ class DenoiserKernels:
         B, L = self._train_shape
         grad_y, film = _f32(grad_y), _f32(film)
         if not self._packT_fresh:
-            if self._packT is None:
-                self._packT = torch.empty(lib().td_rnn_packT_bytes(C.byref(self.cfg)), dtype=torch.uint8, device=self.device)
             check(lib().td_rnn_pack_weights_T(C.byref(self.cfg), ptr_table(self._lw), ptr(self._packT), _stream()))
             self._packT_fresh = True
         if sink is None:
@@ -207,10 +215,11 @@ class DiffusionKernels:
         self.cfg = cfg
         self._loss_ws = torch.empty(lib().td_mixed_loss_workspace_bytes(C.byref(cfg), 1), dtype=torch.uint8, device=device)
 
-    def _rng(self, seed=0, patient0=0, tag=0):
-        return Rng(seed=seed, patient0=patient0, tag=tag)
+    def _rng(self, seed=0, patient0=0, tag=0, seed_dev=None):
+        return Rng(seed=seed, patient0=patient0, tag=tag, seed_dev=None if seed_dev is None else seed_dev.data_ptr())
 
-    def q_sample(self, data, t, noise=None, uniforms=None, seed=0, patient0=0, tag=0):
+    def q_sample(self, data, t, noise=None, uniforms=None, seed=0, patient0=0, tag=0, seed_dev=None):
+        """seed_dev: a device tensor whose first 8 bytes are added to `seed` when the kernel runs (captured training steps)."""
         data = _f32(data)
         B = data.shape[0]
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
@@ -221,7 +230,7 @@ class DiffusionKernels:
         noise = None if noise is None else _f32(noise)
         uniforms = None if uniforms is None else _f32(uniforms)
         check(lib().td_q_sample_mixed(C.byref(self.cfg), B, ptr(data), ptr(t), ptr(noise), ptr(uniforms),
-                                      self._rng(seed, patient0, tag), ptr(x_in), ptr(x0_idx), ptr(xt_idx), ptr(noise_out),
+                                      self._rng(seed, patient0, tag, seed_dev), ptr(x_in), ptr(x0_idx), ptr(xt_idx), ptr(noise_out),
                                       _stream()))
         return x_in, x0_idx, xt_idx, noise_out
 
