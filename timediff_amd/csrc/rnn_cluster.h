@@ -16,6 +16,29 @@ __device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsi
     return ((unsigned long long)tag << 32) | payload;
 }
 
+// Two neighbouring granules as ONE 16-byte write-through store (global_store_dwordx4 sc1): an 8-byte sc1 store is one
+// fabric write per lane, so a pair written separately costs twice the writes; each 8-byte half carries its own tag, so the
+// halves need not land together.  The s_nop covers the hazard of a store of more than 8 bytes whose data registers the next
+// VALU instruction overwrites: the compiler's hazard recognizer does not look inside inline asm (it scheduled a v_mov_dpp
+// into the data registers right behind the store, and the store then wrote the new value).
+typedef __attribute__((ext_vector_type(4))) unsigned tdc_u32x4;
+__device__ __forceinline__ void tdc_store16_sc1(void *ptr, tdc_u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void tdc_store_granule_pair(unsigned long long *dst, unsigned long long bits, unsigned tag) {
+    tdc_store16_sc1(dst, tdc_u32x4{(unsigned)bits, tag, (unsigned)(bits >> 32), tag});
+}
+
+// The receiving side of a granule pair: ONE 16-byte load that bypasses this CU's L1 (buffer_load_dwordx4 sc1; the compiler
+// tracks its completion like any load's).  8-byte accesses run at 0.54-0.70 of the 16-byte rate, and a step's sweep is
+// bound by the number of loads in flight.  `bytes` bounds the descriptor: a load beyond it returns zeros, never faults.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tdc_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ tdc_u32x4 tdc_load_granule_pair(__amdgpu_buffer_rsrc_t r, unsigned byte_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 16 /* sc1 */);
+}
+
 // Workgroup -> (cluster, member).  Workgroups go to the 8 XCDs round-robin by their index, so the natural order
 // (member = index % NU) would spread a cluster over all XCDs.  This map puts the NU members of a cluster on ONE XCD:
 // index = cluster % 8 + 8 * member + 8 * NU * (cluster / 8), in a grid rounded up to whole groups of 8 clusters whose

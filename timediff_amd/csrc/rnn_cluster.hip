@@ -200,13 +200,7 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
     } else if (s + 1 < p.L) {   // publish: two granules per lane, tag = (epoch, s + 1)
         unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + ((size_t)(c * TDC_WAVES + w) * 64 + lane) * 2;
         const unsigned tag = tag0 | (unsigned)(s + 1);
-#ifndef TDC_DBG_PLAINSTORE
-        __hip_atomic_store(dst, tdc_granule((unsigned)hbits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, tdc_granule((unsigned)(hbits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        dst[0] = tdc_granule((unsigned)hbits, tag);
-        dst[1] = tdc_granule((unsigned)(hbits >> 32), tag);
-#endif
+        tdc_store_granule_pair(dst, hbits, tag);
     }
     // the layer's output (next layer / head / weight gradients read it after this launch)
     *(unsigned long long *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + 2 * c + (w >> 1)) * TD_FRAG_BYTES + lane * 16 +
@@ -218,12 +212,23 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
     }
 }
 
+#ifdef TDC_TRACE   // diagnostic build only (tools/cluster_trace.py): wall-clock stamps (10 ns) of one wave's step phases
+__device__ unsigned long long g_tdc_trace[4096 * 8];
+#define TDC_TSTAMP(k) do { if (trace_on) g_tdc_trace[(s & 4095) * 8 + (k)] = wall_clock64(); } while (0)
+#define TDC_TSTAMP_V(k, v) do { if (trace_on) g_tdc_trace[(s & 4095) * 8 + (k)] = (v); } while (0)
+extern "C" __attribute__((visibility("default"))) int td_debug_cluster_trace(unsigned long long *dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tdc_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TDC_TSTAMP(k) do { } while (0)
+#define TDC_TSTAMP_V(k, v) do { } while (0)
+#endif
+
 template <int NU, int XF, bool L0, bool GRU, bool SAVE>
 __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams p) {
     constexpr int KH = 2 * NU;                       // recurrent k-steps
     constexpr int NFR = KH + XF;                     // weight fragments per wave (layer 0: XF = 2 kx0 hi/lo fragments)
     constexpr int XSTAGE = L0 ? 0 : XF;              // input fragments staged in LDS per step
-    constexpr int NPOLL = NU * TDC_WAVES * 64 * 2 / 256;   // granules per thread and step
     constexpr int XLOAD = XSTAGE / TDC_WAVES;        // input fragments each wave brings in per step
     static_assert(L0 || XF % TDC_WAVES == 0, "input fragments must split over the waves");
     __shared__ __attribute__((aligned(16))) char lds[KH * TD_FRAG_BYTES + 2 * (XSTAGE ? XSTAGE : 1) * TD_FRAG_BYTES];
@@ -235,6 +240,9 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
     if (!tdc_block_map(blockIdx.x, p.dirs * p.ngroups, NU, &grp, &c)) return;
     const int dir = grp % p.dirs, gi = grp / p.dirs;
     const int nblk = (p.nbb - gi + p.ngroups - 1) / p.ngroups;   // batch blocks of this cluster (>= 1)
+#ifdef TDC_TRACE
+    const bool trace_on = grp == 0 && c == 1 && tid == 0;
+#endif
 
     // ---- weights: once, into registers --------------------------------------------------------------------
     const char *wsl = p.wpacked + (size_t)dir * p.dir_stride + (size_t)(c * TDC_WAVES + w) * tdc_slice_bytes(NFR);
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
         for (int j = 0; j < nblk; ++j, ++it) {
             const int bb = gi + j * p.ngroups;
             __syncthreads();     // xbuf[it & 1] is complete; every wave is done with hbuf and with xbuf[(it + 1) & 1]
+            TDC_TSTAMP(0);
             // next iteration's inputs: in flight during this one, written to LDS at its end
             const bool more = j + 1 < nblk || s + 1 < p.L;
             if (more) {
@@ -294,12 +303,13 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
             if (nblk > 1) state = s > 0 ? *(const f32x4 *)cptr : f32x4{0.f, 0.f, 0.f, 0.f};
             // (a) h_{s-1} of this block from every workgroup of the cluster: issue the granule loads now, look at them after
             //     the input MFMAs
-            const unsigned long long *src = xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128);   // parity of step s - 1
-            unsigned long long gr[NPOLL];
+            //     (thread (w, lane) takes the granule pair of lane `lane`, wave w of every workgroup n: its 8 bytes of h)
+            const __amdgpu_buffer_rsrc_t src = tdc_rsrc(xch + (size_t)((s + 1) & 1) * (NU * TDC_WAVES * 128), NU * TDC_WAVES * 128 * 8);   // parity of step s - 1
+            const unsigned goff = (unsigned)(w * 64 + lane) * 16;
+            tdc_u32x4 gr[NU];
             if (s > 0) {
 #pragma unroll
-                for (int n = 0; n < NPOLL; ++n)
-                    gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int n = 0; n < NU; ++n) gr[n] = tdc_load_granule_pair(src, goff + n * (TDC_WAVES * 64 * 16));
             }
             // (b) input projection of this step
             f32x16 acc = bias;
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
                 const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)(it & 1) * XSTAGE * TD_FRAG_BYTES) + lane;
                 tdc_mfma_stream<XF, KH, NFR>(acc, W, xs);
             }
+            TDC_TSTAMP(1);
             // (c) complete the hand-off: every granule must carry the tag of step s - 1
             if (s > 0) {
                 const unsigned want = tag0 | (unsigned)s;      // h_{s-1} was published with tag (epoch, s)
@@ -323,30 +334,35 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_kernel(TdClusterParams 
                 while (!dead) {
                     bool ok = true;
 #pragma unroll
-                    for (int n = 0; n < NPOLL; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
+                    for (int n = 0; n < NU; ++n) ok = ok && gr[n].y == want && gr[n].w == want;
                     if (ok) break;
                     if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
                     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                    for (int n = 0; n < NPOLL; ++n)
-                        if ((unsigned)(gr[n] >> 32) != want)
-                            gr[n] = __hip_atomic_load(src + tid + 256 * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int n = 0; n < NU; ++n)
+                        if (gr[n].y != want || gr[n].w != want) gr[n] = tdc_load_granule_pair(src, goff + n * (TDC_WAVES * 64 * 16));
                 }
-                // granule g = ((c' * 4 + w') * 64 + lane') * 2 + e  ->  fragment 2c' + (w' >> 1), lane', bytes 8 (w' & 1) + 4 e
+                TDC_TSTAMP(2);
+                TDC_TSTAMP_V(6, (unsigned long long)spins);
+                // the pair of (workgroup n, wave w, lane)  ->  fragment 2n + (w >> 1), lane, bytes 8 (w & 1) .. + 8
 #pragma unroll
-                for (int n = 0; n < NPOLL; ++n) {
-                    const int g = tid + 256 * n;
-                    const int e = g & 1, ln = (g >> 1) & 63, wp = (g >> 7) & 3, cp = g >> 9;
-                    *(unsigned *)(hbuf + (size_t)(2 * cp + (wp >> 1)) * TD_FRAG_BYTES + ln * 16 + 8 * (wp & 1) + 4 * e) = (unsigned)gr[n];
-                }
+                for (int n = 0; n < NU; ++n)
+                    *(unsigned long long *)(hbuf + (size_t)(2 * n + (w >> 1)) * TD_FRAG_BYTES + lane * 16 + 8 * (w & 1)) =
+                        ((unsigned long long)gr[n].z << 32) | gr[n].x;
             }
             __syncthreads();     // h_{s-1} is in LDS as B fragments
+            TDC_TSTAMP(3);
             // (d) recurrent part
             if (s > 0) {
                 const bf16x8 *hs = (const bf16x8 *)hbuf + lane;
                 tdc_mfma_stream<KH, 0, NFR>(acc, W, hs);
             }
+#ifdef TDC_TRACE
+            asm volatile("s_nop 0" :: "v"(acc[0]));
+#endif
+            TDC_TSTAMP(4);
             tdc_finish_step<NU, GRU, SAVE>(p, acc, state, dead, nblk > 1 && s + 1 < p.L ? cptr : nullptr, xch, tag0, s, l, bb, dir, c, w, lane);
+            TDC_TSTAMP(5);
             if (more) x_commit((it + 1) & 1);
         }
     }

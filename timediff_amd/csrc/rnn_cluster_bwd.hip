@@ -25,14 +25,6 @@
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tdc_bf16x4;
 
-// 16-byte write-through store (global_store_dwordx4 sc1): the form the bandwidth hand-off below is built on
-typedef __attribute__((ext_vector_type(4))) unsigned tdc_u32x4;
-// The s_nop covers the hazard of a store of more than 8 bytes whose data registers the next VALU instruction overwrites:
-// the compiler's hazard recognizer does not look inside inline asm (it scheduled a v_mov_dpp into the data registers
-// right behind the store, and the store then wrote the new value).
-__device__ __forceinline__ void tdc_store16_sc1(void *ptr, tdc_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
-}
 // the value of the neighbouring lane (lane ^ 1)
 __device__ __forceinline__ unsigned tdc_swap1(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
 
@@ -43,6 +35,18 @@ __device__ __forceinline__ unsigned tdc_swap1(unsigned x) { return (unsigned)__b
 // one wave behind the next iteration's workgroup barrier, after every wave's s_waitcnt vmcnt(0); the receiver polls the
 // 8 flags of its block and then reads the payload with 8-byte sc1 loads (MI355X_MICROARCH.md, hand-offs with sc1 loads
 // in place of the acquire, first row).
+#ifdef TDC_TRACE   // diagnostic build only (tools/cluster_trace.py): wall-clock stamps (10 ns) of one wave's step phases
+__device__ unsigned long long g_tdc_btrace[4096 * 8];
+#define TDC_TSTAMP(k) do { if (trace_on) g_tdc_btrace[(s & 4095) * 8 + (k)] = wall_clock64(); } while (0)
+#define TDC_TSTAMP_V(k, v) do { if (trace_on) g_tdc_btrace[(s & 4095) * 8 + (k)] = (v); } while (0)
+extern "C" __attribute__((visibility("default"))) int td_debug_bptt_trace(unsigned long long *dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tdc_btrace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TDC_TSTAMP(k) do { } while (0)
+#define TDC_TSTAMP_V(k, v) do { } while (0)
+#endif
+
 template <int NU, bool GRU, bool MULTI>
 __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdParams p) {
     constexpr int KH = 2 * NU, NT = GRU ? 3 : 4;
@@ -60,6 +64,9 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
     if (!tdc_block_map(blockIdx.x, p.dirs * p.ngroups, NU, &grp, &c)) return;
     const int dir = grp % p.dirs, gi0 = grp / p.dirs;
     const int nblk = (p.nbb - gi0 + p.ngroups - 1) / p.ngroups;   // batch blocks gi0, gi0 + ngroups, ... (>= 1)
+#ifdef TDC_TRACE
+    const bool trace_on = grp == 0 && c == 1 && tid == 0;
+#endif
 
     // ---- this workgroup's slice of W_hh^T: rows = every hidden unit (the wave's two row blocks), k = its own 32 units
     bf16x8 W[RBW][NT][2];
@@ -85,13 +92,15 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
     auto inbox_of = [&](int bb) { return p.inbox + (size_t)(dir * p.nbb + bb) * 2 * PAR; };
     // MULTI: [parity][dst][src] flag words of a block, behind the payload of all blocks and directions
     auto flags_of = [&](int bb) { return (unsigned *)(p.inbox + (size_t)p.dirs * p.nbb * 2 * PAR) + (size_t)(dir * p.nbb + bb) * 2 * NU * NU; };
-    // the partial sums for this wave's units of (step s, block bb): one load of each granule (re-read below while stale)
-    unsigned long long gr[2 * NU];
-    auto poll_issue = [&](int s, int bb) {
-        const unsigned long long *src = inbox_of(bb) + (size_t)((s - 1) & 1) * PAR + ((size_t)(c * NU) * TDC_WAVES + w) * 128 + lane * 2;
+    // the partial sums for this wave's units of (step s, block bb) from every source workgroup n: one granule pair each
+    // (re-read below while stale), out of this workgroup's [src][wave][lane] slab of the parity buffer
+    tdc_u32x4 gr[NU];
+    constexpr unsigned SLAB = NU * TDC_WAVES * 128 * 8;      // bytes per destination workgroup and parity
+    const unsigned goff = (unsigned)(w * 64 + lane) * 16;
+    auto poll_src = [&](int s, int bb) { return tdc_rsrc(inbox_of(bb) + (size_t)((s - 1) & 1) * PAR + (size_t)c * (SLAB / 8), SLAB); };
+    auto poll_issue = [&](__amdgpu_buffer_rsrc_t src) {
 #pragma unroll
-        for (int n = 0; n < 2 * NU; ++n)
-            gr[n] = __hip_atomic_load(src + (size_t)(n >> 1) * (TDC_WAVES * 128) + (n & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int n = 0; n < NU; ++n) gr[n] = tdc_load_granule_pair(src, goff + n * (TDC_WAVES * 64 * 16));
     };
     // what an iteration needs from memory, fetched one iteration ahead
     f32x4 sv[5], pv;
@@ -126,6 +135,34 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
         for (int j = 0; j < nblk; ++j, ++it) {
             const int bb = gi0 + j * p.ngroups, par = it & 1;
             unsigned long long *inbox = inbox_of(bb);
+            TDC_TSTAMP(0);
+            // the factors of the gate gradients that do not depend on d h_t (from the saved gate values of this step)
+            float gf[6][4];
+            auto gate_factors = [&]() {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float prev = pv[i];
+                    if constexpr (!GRU) {
+                        const float ig = sv[0][i], fg = sv[1][i], gg = sv[2][i], og = sv[3][i], cv = sv[4][i];
+                        const float tc = td_tanh(cv);
+                        gf[0][i] = gg * ig * (1.0f - ig);
+                        gf[1][i] = prev * fg * (1.0f - fg);
+                        gf[2][i] = ig * (1.0f - gg * gg);
+                        gf[3][i] = tc * og * (1.0f - og);
+                        gf[4][i] = og * (1.0f - tc * tc);      // d c += d h * this
+                        gf[5][i] = fg;                         // carry = d c * f
+                    } else {
+                        const float rg = sv[0][i], zg = sv[1][i], ng = sv[2][i], hn = sv[3][i];
+                        const float an = (1.0f - zg) * (1.0f - ng * ng);
+                        gf[0][i] = an * hn * rg * (1.0f - rg);
+                        gf[1][i] = (prev - ng) * zg * (1.0f - zg);
+                        gf[2][i] = an;
+                        gf[3][i] = an * rg;
+                        gf[4][i] = 0.f;
+                        gf[5][i] = zg;
+                    }
+                }
+            };
             // ---- d h_t: gradient from above + the cluster's partial sums of W_hh^T d a_{t+1} -----------------------------
             f32x4 dh;
             {
@@ -134,29 +171,33 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                 for (int i = 0; i < 4; ++i) dh[i] = (float)a[i] + (float)b[i];
             }
             if (s > 0 && !MULTI) {
-                const unsigned long long *src = inbox + (size_t)((s - 1) & 1) * PAR + ((size_t)(c * NU) * TDC_WAVES + w) * 128 + lane * 2;
+                const __amdgpu_buffer_rsrc_t src = poll_src(s, bb);
                 const unsigned want = tag0 | (unsigned)s;          // partial sums of step s - 1 carry the tag (epoch, s)
-                poll_issue(s, bb);
+                poll_issue(src);
+                gate_factors();                                     // what needs no d h: under the hand-off's flight
                 int spins = 0;
                 while (!dead) {
                     bool ok = true;
 #pragma unroll
-                    for (int n = 0; n < 2 * NU; ++n) ok = ok && (unsigned)(gr[n] >> 32) == want;
+                    for (int n = 0; n < NU; ++n) ok = ok && gr[n].y == want && gr[n].w == want;
                     if (ok) break;
                     if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
                     __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                    for (int n = 0; n < 2 * NU; ++n)
-                        if ((unsigned)(gr[n] >> 32) != want)
-                            gr[n] = __hip_atomic_load(src + (size_t)(n >> 1) * (TDC_WAVES * 128) + (n & 1), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
+                    for (int n = 0; n < NU; ++n)
+                        if (gr[n].y != want || gr[n].w != want) gr[n] = tdc_load_granule_pair(src, goff + n * (TDC_WAVES * 64 * 16));
                 }
+                TDC_TSTAMP(1);
+                TDC_TSTAMP_V(6, (unsigned long long)spins);
 #pragma unroll
-                for (int n = 0; n < 2 * NU; ++n) {
-                    const unsigned pl = (unsigned)gr[n];
-                    dh[2 * (n & 1)] += __builtin_bit_cast(float, pl << 16);
-                    dh[2 * (n & 1) + 1] += __builtin_bit_cast(float, pl & 0xffff0000u);
+                for (int n = 0; n < NU; ++n) {
+                    dh[0] += __builtin_bit_cast(float, gr[n].x << 16);
+                    dh[1] += __builtin_bit_cast(float, gr[n].x & 0xffff0000u);
+                    dh[2] += __builtin_bit_cast(float, gr[n].z << 16);
+                    dh[3] += __builtin_bit_cast(float, gr[n].z & 0xffff0000u);
                 }
+            } else {
+                gate_factors();
             }
             if (s > 0 && MULTI) {
                 // the 8 sources' flags of (step s - 1, this block, this workgroup): lanes 0 .. NU - 1 poll one each
@@ -186,29 +227,25 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                 }
             }
             if (nblk > 1) carry = carry_lds[j * 256 + tid];
-            // ---- gate gradients of this lane's 4 units --------------------------------------------------------------------
+            // ---- gate gradients of this lane's 4 units: d a = (d h, carry) times the factors -----------------------------
             float da[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float g = dh[i], prev = pv[i];
+                const float g = dh[i];
                 if constexpr (!GRU) {
-                    const float ig = sv[0][i], fg = sv[1][i], gg = sv[2][i], og = sv[3][i], cv = sv[4][i];
-                    const float tc = td_tanh(cv);
-                    const float dcv = carry[i] + g * og * (1.0f - tc * tc);
-                    da[0][i] = dcv * gg * ig * (1.0f - ig);
-                    da[1][i] = dcv * prev * fg * (1.0f - fg);
-                    da[2][i] = dcv * ig * (1.0f - gg * gg);
-                    da[3][i] = g * tc * og * (1.0f - og);
-                    carry[i] = dcv * fg;
+                    const float dcv = carry[i] + g * gf[4][i];
+                    da[0][i] = dcv * gf[0][i];
+                    da[1][i] = dcv * gf[1][i];
+                    da[2][i] = dcv * gf[2][i];
+                    da[3][i] = g * gf[3][i];
+                    carry[i] = dcv * gf[5][i];
                 } else {
-                    const float rg = sv[0][i], zg = sv[1][i], ng = sv[2][i], hn = sv[3][i];
                     const float dht = g + carry[i];
-                    const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
-                    da[0][i] = dan * hn * rg * (1.0f - rg);
-                    da[1][i] = dht * (prev - ng) * zg * (1.0f - zg);
-                    da[2][i] = dan;
-                    da[3][i] = dan * rg;
-                    carry[i] = dht * zg;
+                    da[0][i] = dht * gf[0][i];
+                    da[1][i] = dht * gf[1][i];
+                    da[2][i] = dht * gf[2][i];
+                    da[3][i] = dht * gf[3][i];
+                    carry[i] = dht * gf[5][i];
                 }
             }
             if (nblk > 1) carry_lds[j * 256 + tid] = carry;
@@ -226,20 +263,28 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
             // among them (nothing younger than the loads just consumed is in flight: the wait is free)
             if constexpr (MULTI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- d a_t: to LDS for the cluster's product, to HBM for the batched GEMMs after the sweep ---------------------------
-            {
+            // (the HBM copies go out here, ahead of the barrier: issued behind the send they delayed the next step's poll loads,
+            // which queue behind them, by more than they cost here -- 3.24 against 3.04 us per step, profiles/round3_cluster_steps.md)
+            tdc_bf16x4 dab[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                dab[gi] = tdc_bf16x4{(__bf16)da[gi][0], (__bf16)da[gi][1], (__bf16)da[gi][2], (__bf16)da[gi][3]};
+                *(unsigned long long *)(lds + (size_t)(par * 8 + gi * 2 + (w >> 1)) * TD_FRAG_BYTES + sub) = *(const unsigned long long *)&dab[gi];
+            }
+            auto store_da = [&]() {
                 char *fbase = p.daf + (size_t)dir * p.daf_dir + (((size_t)l * p.nbb + bb) * 4 * KH + kfrag) * TD_FRAG_BYTES + sub;
                 __bf16 *pl = p.dapl + (size_t)dir * p.dapl_dir + (size_t)(32 * c + 8 * w + 4 * hf) * cols + (size_t)l * p.nbb * 32 + bb * 32 + m;
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
-                    const tdc_bf16x4 v = {(__bf16)da[gi][0], (__bf16)da[gi][1], (__bf16)da[gi][2], (__bf16)da[gi][3]};
-                    const unsigned long long bits = *(const unsigned long long *)&v;
-                    *(unsigned long long *)(lds + (size_t)(par * 8 + gi * 2 + (w >> 1)) * TD_FRAG_BYTES + sub) = bits;
-                    *(unsigned long long *)(fbase + (size_t)gi * KH * TD_FRAG_BYTES) = bits;
+                    *(unsigned long long *)(fbase + (size_t)gi * KH * TD_FRAG_BYTES) = *(const unsigned long long *)&dab[gi];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pl[((size_t)gi * hpad + i) * cols] = v[i];
+                    for (int i = 0; i < 4; ++i) pl[((size_t)gi * hpad + i) * cols] = dab[gi][i];
                 }
-            }
+            };
+            store_da();
+            TDC_TSTAMP(2);
             __syncthreads();     // d a_t of the 32 units is in LDS (the other parity is free again two iterations on)
+            TDC_TSTAMP(3);
             if constexpr (MULTI) {
                 // behind the barrier every wave's payload stores of the iteration before are complete: raise its flags
                 if (w == 0 && lane < NU && pend_tag) __hip_atomic_store(pend_flags + lane * NU + c, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -271,6 +316,10 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                     for (int rbi = 0; rbi < RBW; ++rbi)
                         acc[rbi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[rbi][t][half], B[slab][half], acc[rbi], 0, 0, 0);
             }
+#ifdef TDC_TRACE
+            asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[RBW - 1][15]));
+#endif
+            TDC_TSTAMP(4);
             // ---- send: accumulator registers 4w' .. 4w' + 3 of row block rb belong to wave w' of workgroup rb, same lane ---------
             if constexpr (!MULTI) {
                 const unsigned tag = tag0 | (unsigned)(s + 1);
@@ -282,11 +331,10 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                         const tdc_bf16x4 v = {(__bf16)acc[rbi][4 * wp], (__bf16)acc[rbi][4 * wp + 1], (__bf16)acc[rbi][4 * wp + 2],
                                               (__bf16)acc[rbi][4 * wp + 3]};
                         const unsigned long long bits = *(const unsigned long long *)&v;
-                        __hip_atomic_store(dst + wp * 128, tdc_granule((unsigned)bits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dst + wp * 128 + 1, tdc_granule((unsigned)(bits >> 32), tag), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                        tdc_store_granule_pair(dst + wp * 128, bits, tag);
                     }
                 }
+                TDC_TSTAMP(5);
             } else {
                 const bool odd = lane & 1;
 #pragma unroll
