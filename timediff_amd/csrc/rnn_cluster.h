@@ -16,17 +16,17 @@ __device__ __forceinline__ unsigned long long tdc_granule(unsigned payload, unsi
     return ((unsigned long long)tag << 32) | payload;
 }
 
-// Two neighbouring granules as ONE 16-byte write-through store (global_store_dwordx4 sc1): an 8-byte sc1 store is one
+// Two neighbouring granules as ONE 16-byte write-through store (buffer_store_dwordx4 sc1): an 8-byte sc1 store is one
 // fabric write per lane, so a pair written separately costs twice the writes; each 8-byte half carries its own tag, so the
-// halves need not land together.  The s_nop covers the hazard of a store of more than 8 bytes whose data registers the next
-// VALU instruction overwrites: the compiler's hazard recognizer does not look inside inline asm (it scheduled a v_mov_dpp
-// into the data registers right behind the store, and the store then wrote the new value).
+// halves need not land together.  A buffer store from the builtin, not inline asm: the compiler counts it when it places
+// its vmcnt waits (an asm store is invisible to that count, and a wait for an older load then also waits for the store) and
+// covers the data-register hazard of stores wider than 8 bytes itself.  `base` must be wave-uniform.
 typedef __attribute__((ext_vector_type(4))) unsigned tdc_u32x4;
-__device__ __forceinline__ void tdc_store16_sc1(void *ptr, tdc_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+__device__ __forceinline__ void tdc_store16_sc1(const void *base, unsigned byte_offset, tdc_u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, -1, 0x00020000), (int)byte_offset, 0, 16 /* sc1 */);
 }
-__device__ __forceinline__ void tdc_store_granule_pair(unsigned long long *dst, unsigned long long bits, unsigned tag) {
-    tdc_store16_sc1(dst, tdc_u32x4{(unsigned)bits, tag, (unsigned)(bits >> 32), tag});
+__device__ __forceinline__ void tdc_store_granule_pair(const void *base, unsigned byte_offset, unsigned long long bits, unsigned tag) {
+    tdc_store16_sc1(base, byte_offset, tdc_u32x4{(unsigned)bits, tag, (unsigned)(bits >> 32), tag});
 }
 
 // The receiving side of a granule pair: ONE 16-byte load that bypasses this CU's L1 (buffer_load_dwordx4 sc1; the compiler

@@ -198,9 +198,9 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
     if (cptr) *(f32x4 *)cptr = state;
     if constexpr (PAYLOAD) {
     } else if (s + 1 < p.L) {   // publish: two granules per lane, tag = (epoch, s + 1)
-        unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + ((size_t)(c * TDC_WAVES + w) * 64 + lane) * 2;
+        const unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + (size_t)(c * TDC_WAVES + w) * 128;
         const unsigned tag = tag0 | (unsigned)(s + 1);
-        tdc_store_granule_pair(dst, hbits, tag);
+        tdc_store_granule_pair(dst, (unsigned)lane * 16, hbits, tag);
     }
     // the layer's output (next layer / head / weight gradients read it after this launch)
     *(unsigned long long *)(p.out + (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + 2 * c + (w >> 1)) * TD_FRAG_BYTES + lane * 16 +

@@ -129,6 +129,33 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
     bool dead = false;
     unsigned *pend_flags = nullptr;     // MULTI: flags of the payload sent in the iteration before, raised behind the next barrier
     unsigned pend_tag = 0;
+    // MULTI, several blocks per cluster: an iteration's partial sums were sent a round of blocks ago, so they are fetched one
+    // iteration ahead (under the MFMAs of the iteration before, like the saved gate values), behind flags that were read one
+    // iteration earlier still: a flag read or a payload read is an L2 round trip of 1 - 2 us even when the data has long been
+    // there, and at the top of the iteration nothing hides it (measured: 3.57 us per iteration with both there).
+    unsigned long long pay[NU];
+    bool pay_ready = false;             // pay[] holds the partial sums of the iteration that begins
+    unsigned fnext = 0;                 // the flags of the iteration after next, as read one iteration ahead
+    auto flag_word = [&](int s2, int bb2) { return flags_of(bb2) + (size_t)((s2 - 1) & 1) * NU * NU + c * NU + (lane & (NU - 1)); };
+    auto await_flags = [&](int s2, int bb2, unsigned f, bool have) {     // the 8 sources' flags of (step s2 - 1, block bb2): lanes poll one each
+        const unsigned *fl = flag_word(s2, bb2);
+        const unsigned want = tag0 | (unsigned)s2;
+        int spins = 0;
+        while (!dead) {
+            if (have && __builtin_amdgcn_ballot_w64(f != want) == 0) break;
+            if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
+            if (spins > 1) __builtin_amdgcn_s_sleep(1);
+            f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = true;
+        }
+        asm volatile("" ::: "memory");      // the payload loads stay behind the poll
+    };
+    auto load_payload = [&](int s2, int bb2) {
+        // payload [parity][dst][src][wave][lane] x 8 bytes (4 bf16): this lane's 4 units from every source
+        const unsigned long long *src = inbox_of(bb2) + (size_t)((s2 - 1) & 1) * (PAR / 2) + ((size_t)(c * NU) * TDC_WAVES + w) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NU; ++n) pay[n] = __hip_atomic_load(src + (size_t)n * (TDC_WAVES * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     int it = 0;                  // iteration = (step s, block j): the LDS staging alternates with its parity
     for (int s = 0; s < p.L; ++s) {
         const int l = lpos(s);
@@ -200,23 +227,10 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                 gate_factors();
             }
             if (s > 0 && MULTI) {
-                // the 8 sources' flags of (step s - 1, this block, this workgroup): lanes 0 .. NU - 1 poll one each
-                const unsigned *fl = flags_of(bb) + (size_t)((s - 1) & 1) * NU * NU + c * NU + (lane & (NU - 1));
-                const unsigned want = tag0 | (unsigned)s;
-                int spins = 0;
-                while (!dead) {
-                    const unsigned f = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__builtin_amdgcn_ballot_w64(f != want) == 0) break;
-                    if (++spins > TDC_SPIN_LIMIT) { dead = true; TDC_RAISE(p); break; }
-                    __builtin_amdgcn_s_sleep(1);
+                if (!pay_ready) {       // a cluster with one block: its sums were sent in the iteration before
+                    await_flags(s, bb, 0u, false);
+                    load_payload(s, bb);
                 }
-                asm volatile("" ::: "memory");      // the payload loads stay behind the poll
-                // payload [parity][dst][src][wave][lane] x 8 bytes (4 bf16): this lane's 4 units from every source
-                const unsigned long long *src = inbox + (size_t)((s - 1) & 1) * (PAR / 2) + ((size_t)(c * NU) * TDC_WAVES + w) * 64 + lane;
-                unsigned long long pay[NU];
-#pragma unroll
-                for (int n = 0; n < NU; ++n)
-                    pay[n] = __hip_atomic_load(src + (size_t)n * (TDC_WAVES * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int n = 0; n < NU; ++n) {
                     const unsigned lo = (unsigned)pay[n], hi = (unsigned)(pay[n] >> 32);
@@ -225,6 +239,10 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                     dh[2] += __builtin_bit_cast(float, hi << 16);
                     dh[3] += __builtin_bit_cast(float, hi & 0xffff0000u);
                 }
+#ifdef TDC_TRACE
+                asm volatile("s_nop 0" :: "v"(dh[0]), "v"(dh[3]));
+                TDC_TSTAMP(1);
+#endif
             }
             if (nblk > 1) carry = carry_lds[j * 256 + tid];
             // ---- gate gradients of this lane's 4 units: d a = (d h, carry) times the factors -----------------------------
@@ -259,9 +277,6 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
             for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dbacc[gi][i] += da[gi][i];
-            // MULTI: every vector-memory operation of this wave so far has completed, the payload stores of the iteration before
-            // among them (nothing younger than the loads just consumed is in flight: the wait is free)
-            if constexpr (MULTI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- d a_t: to LDS for the cluster's product, to HBM for the batched GEMMs after the sweep ---------------------------
             // (the HBM copies go out here, ahead of the barrier: issued behind the send they delayed the next step's poll loads,
             // which queue behind them, by more than they cost here -- 3.24 against 3.04 us per step, profiles/round3_cluster_steps.md)
@@ -281,19 +296,35 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                     for (int i = 0; i < 4; ++i) pl[((size_t)gi * hpad + i) * cols] = dab[gi][i];
                 }
             };
-            store_da();
+            if constexpr (!MULTI) store_da();
+            // MULTI: every vector-memory operation of this wave so far has completed, the payload stores of the iteration before
+            // among them (they are the youngest in flight: the loads issued before them were consumed above, and this
+            // iteration's HBM copies of d a go out behind the barrier so that this wait does not cover them)
+            if constexpr (MULTI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TDC_TSTAMP(2);
             __syncthreads();     // d a_t of the 32 units is in LDS (the other parity is free again two iterations on)
             TDC_TSTAMP(3);
+            const bool last_blk = j + 1 == nblk;
+            const int s2 = last_blk ? s + 1 : s, bb2 = last_blk ? gi0 : bb + p.ngroups;
             if constexpr (MULTI) {
                 // behind the barrier every wave's payload stores of the iteration before are complete: raise its flags
                 if (w == 0 && lane < NU && pend_tag) __hip_atomic_store(pend_flags + lane * NU + c, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pend_tag = 0;
+                store_da();
             }
             // ---- the next iteration's operands: in flight under this one's MFMAs --------------------------------------------------
-            const bool last_blk = j + 1 == nblk;
-            const int s2 = last_blk ? s + 1 : s, bb2 = last_blk ? gi0 : bb + p.ngroups;
             if (s2 < p.L) prefetch(s2, bb2);
+            if constexpr (MULTI) {
+                pay_ready = false;
+                if (nblk > 1 && s2 > 0 && s2 < p.L) {
+                    await_flags(s2, bb2, fnext, true);
+                    load_payload(s2, bb2);
+                    pay_ready = true;
+                    const bool last2 = bb2 + p.ngroups >= p.nbb;
+                    const int s3 = last2 ? s2 + 1 : s2, bb3 = last2 ? gi0 : bb2 + p.ngroups;
+                    fnext = (s3 > 0 && s3 < p.L) ? __hip_atomic_load(flag_word(s3, bb3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                }
+            }
             if (s + 1 >= p.L) continue;
             // ---- partial sums of W_hh^T d a_t over this workgroup's 32 units, for every hidden unit ------------------------------
             bf16x8 B[4][2];
@@ -325,13 +356,13 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                 const unsigned tag = tag0 | (unsigned)(s + 1);
 #pragma unroll
                 for (int rbi = 0; rbi < RBW; ++rbi) {
-                    unsigned long long *dst = inbox + (size_t)(s & 1) * PAR + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 128 + lane * 2;
+                    const unsigned long long *dst = inbox + (size_t)(s & 1) * PAR + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 128;
 #pragma unroll
                     for (int wp = 0; wp < TDC_WAVES; ++wp) {
                         const tdc_bf16x4 v = {(__bf16)acc[rbi][4 * wp], (__bf16)acc[rbi][4 * wp + 1], (__bf16)acc[rbi][4 * wp + 2],
                                               (__bf16)acc[rbi][4 * wp + 3]};
                         const unsigned long long bits = *(const unsigned long long *)&v;
-                        tdc_store_granule_pair(dst + wp * 128, bits, tag);
+                        tdc_store_granule_pair(dst + wp * 128, (unsigned)lane * 16, bits, tag);
                     }
                 }
                 TDC_TSTAMP(5);
@@ -341,8 +372,7 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                 for (int rbi = 0; rbi < RBW; ++rbi) {
                     // [parity][dst][src][wave w'][lane] x 8 bytes; a lane pair writes 16 bytes: the even lane those of wave w' = 2q,
                     // the odd lane those of w' = 2q + 1 (each gets the other's 8 bytes for that wave by DPP)
-                    char *dst = (char *)(inbox + (size_t)(s & 1) * (PAR / 2) + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 64) +
-                                (size_t)(lane & ~1) * 8;
+                    const char *dst = (const char *)(inbox + (size_t)(s & 1) * (PAR / 2) + ((size_t)((RBW * w + rbi) * NU + c) * TDC_WAVES) * 64);
                     unsigned pc[TDC_WAVES][2];
 #pragma unroll
                     for (int wp = 0; wp < TDC_WAVES; ++wp) {
@@ -358,9 +388,10 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
                         const unsigned g1 = tdc_swap1(odd ? pc[2 * q][1] : pc[2 * q + 1][1]);
                         const tdc_u32x4 v = odd ? tdc_u32x4{g0, g1, pc[2 * q + 1][0], pc[2 * q + 1][1]}
                                                 : tdc_u32x4{pc[2 * q][0], pc[2 * q][1], g0, g1};
-                        tdc_store16_sc1(dst + (size_t)(2 * q + (odd ? 1 : 0)) * 512, v);
+                        tdc_store16_sc1(dst + (size_t)(2 * q) * 512, (unsigned)(lane & ~1) * 8 + (odd ? 512u : 0u), v);
                     }
                 }
+                TDC_TSTAMP(5);
                 pend_flags = flags_of(bb) + (size_t)(s & 1) * NU * NU;
                 pend_tag = tag0 | (unsigned)(s + 1);
                 if (nblk == 1) {
