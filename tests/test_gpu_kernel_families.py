@@ -113,6 +113,26 @@ def test_batch_block_family_forced(nu, gru, shape, dev, knob):
     _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
 
 
+@pytest.mark.parametrize("gru", [0, 1])
+@pytest.mark.parametrize("nu", [1, 2, 3])
+@pytest.mark.parametrize("shape", ["bi_c14", "uni_c23"])
+def test_resident_family_forced(nu, gru, shape, dev, knob):
+    """Every instantiation of td_rnn_resident_kernel (widths of up to three unit blocks: the whole layer in one workgroup,
+    weights in registers, h through LDS): <NU, 2|4, L0>, <NU, 2NU|4NU, upper> x GRU x SAVE, exact and padded widths, with
+    a ragged last batch block."""
+    from timediff_amd import _lib
+    knob(_lib.LAYER_KERNEL_CLUSTER)
+    dirs, Cc, n_num = (2, 14, 4) if shape == "bi_c14" else (1, 23, 7)
+    H = NU_WIDTHS[nu][0 if shape == "bi_c14" else 1]
+    B, L, layers = 150, 7, 3
+    sd = random_state(H, Cc, layers, dirs, gru, seed=200 * nu + 10 * gru + dirs)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_CLUSTER
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=nu + 50)
+    gy = (rng.standard_normal((B, Cc, L)) / (B * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
+
+
 # (H, gru, dirs, B): just above the automatic switch to the batch-block kernel
 AUTO_CASES = [
     (256, 0, 2, 8192 + 40),     # bench.py's configuration (BASELINE.json configs[1]/[2]): <8, 1, L0> and <8, 32, upper>
@@ -120,8 +140,8 @@ AUTO_CASES = [
     (128, 0, 2, 8192 + 40),
     (256, 0, 1, 16384 + 40),
     (192, 0, 2, 1024 + 40),
-    (92, 0, 2, 1024 + 40),      # MIMIC-III width (configs[0]) at the large-batch sampler's side of the switch
-    (40, 1, 2, 1024 + 40),      # HiRID-like width
+    (92, 0, 2, 16384 + 40),     # MIMIC-III width (configs[0]) at the large-batch sampler's side of the switch
+    (40, 1, 2, 16384 + 40),     # HiRID-like width
 ]
 
 
@@ -132,7 +152,8 @@ def test_auto_dispatch_above_switch(H, gru, dirs, B, dev):
     sd = random_state(H, Cc, layers, dirs, gru, seed=H + gru)
     den = den_kernels(sd, dev)
     assert _choice(den, B) == _lib.LAYER_KERNEL_BATCH, "this batch should run the batch-block kernel"
-    small = _lib.LAYER_KERNEL_CLUSTER if H > 192 else (_lib.LAYER_KERNEL_UNITS if H > 32 else _lib.LAYER_KERNEL_BATCH)
+    # small batches: the cluster family at the widths it is built for (8 unit blocks over 8 CUs; up to 3 in one workgroup)
+    small = _lib.LAYER_KERNEL_CLUSTER if H > 192 or H <= 96 else _lib.LAYER_KERNEL_UNITS
     assert _choice(den, 64) == small
     x, t, rng = _inputs(B, Cc, L, n_num, seed=H)
     rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(0, B, 97), np.arange(B - 48, B)]))
@@ -223,13 +244,15 @@ FUSED_HEAD = [
 
 
 @pytest.mark.parametrize("H,gru,dirs,Cc,n_num,B", FUSED_HEAD)
-def test_fused_head_matches_head_kernel(H, gru, dirs, Cc, n_num, B, dev, fusion):
+def test_fused_head_matches_head_kernel(H, gru, dirs, Cc, n_num, B, dev, fusion, knob):
     """td_rnn_layer_kernel<..., HEAD> + td_head_combine_kernel against td_head_kernel on the same layers (one FiLM row
     for the batch): both project the same bf16 hidden state with fp32-accurate weights, and against the oracle."""
     from timediff_amd import _lib
     L = 5
     sd = random_state(H, Cc, 2, dirs, gru, seed=H + B)
     den = den_kernels(sd, dev)
+    if H <= 96:
+        knob(_lib.LAYER_KERNEL_BATCH)      # at these widths AUTO keeps the one-workgroup kernel up to 16384 sequences
     assert _choice(den, B, L) == _lib.LAYER_KERNEL_BATCH
     x, _, _ = _inputs(B, Cc, L, n_num, seed=B)
     film = den.time_film(cu(np.array([321]), dev))
@@ -308,7 +331,7 @@ def test_single_layer_cluster_chain_graph_equals_stepwise(T, dev):
 
 def test_cluster_dispatch_and_agreement(dev, knob):
     """AUTO takes the cluster kernel where it can run (hidden 193..256, at most 2048 sequences bidirectional, at least 4
-    steps) and nothing else; its results agree with the unit-split kernel's within the bf16 bound, run to run
+    steps; its one-workgroup form at hidden <= 96: test_resident_family_forced) and nothing else; its results agree with the unit-split kernel's within the bf16 bound, run to run
     bit-identically; forcing it on a shape it cannot run is an error, not a fallback."""
     from timediff_amd import _lib
     sd = random_state(256, 14, 3, 2, 0, seed=3)
@@ -329,9 +352,9 @@ def test_cluster_dispatch_and_agreement(dev, knob):
     assert _choice(den, 600, 9) == _lib.LAYER_KERNEL_CLUSTER and _choice(den, 600, 3) == -1
     with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
         den.forward(cu(np.zeros((6, 14, 3), np.float32), dev), cu(np.zeros(6, np.int64), dev))
-    small = den_kernels(random_state(64, 14, 2, 2, 0, seed=1), dev)
+    mid = den_kernels(random_state(128, 14, 2, 2, 0, seed=1), dev)       # 4 unit blocks: neither form of the cluster kernel
     with pytest.raises(_lib.TimediffError, match="cluster kernel was forced"):
-        small.forward(cu(np.zeros((8, 14, 9), np.float32), dev), cu(np.zeros(8, np.int64), dev))
+        mid.forward(cu(np.zeros((8, 14, 9), np.float32), dev), cu(np.zeros(8, np.int64), dev))
 
 
 @pytest.mark.parametrize("gru", [0, 1])

@@ -11,6 +11,9 @@ int td_head_fusion_mode(void);    // api.cpp
 #ifndef TD_CLUSTER_AUTO_BLOCKS
 #define TD_CLUSTER_AUTO_BLOCKS 128   // x 32 sequences, both directions counted: 2048 bidirectional sequences (training step there 49.4 ms against 52.6 ms with the unit-split forward; equal at 4096)
 #endif
+#ifndef TD_RESIDENT_AUTO_WORKGROUPS
+#define TD_RESIDENT_AUTO_WORKGROUPS 1024   // H <= 96, one workgroup per (batch block, direction): up to this many of them (16384 sequences bidirectional: there the sampler step equals the batch-block family's with its fused head, 0.80 against 0.82 ms at H = 92; at 131072 it loses, 6.78 against 6.25 ms)
+#endif
 // rnn_cluster.hip
 size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb);
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L);
@@ -43,6 +46,7 @@ static bool td_use_cluster(const TdRnnGeom &g, int nbb, int L) {
     if (force == TD_LAYER_KERNEL_BATCH || force == TD_LAYER_KERNEL_UNITS) return false;
     if (!td_cluster_supported(g, nbb, L)) return false;
     if (force == TD_LAYER_KERNEL_CLUSTER) return true;
+    if (g.nu <= TDC_RESIDENT_MAX_NU) return nbb * g.dirs <= TD_RESIDENT_AUTO_WORKGROUPS;
     return nbb <= td_cluster_auto_max_blocks(g);
 }
 
@@ -221,7 +225,7 @@ extern "C" int td_rnn_pack_weights(const td_rnn_config *cfg, const float *const 
         }
     flush();
     TD_LAUNCH_CHECK();
-    if (g.nu == TD_CLUSTER_NU) return td_cluster_pack_all(cfg, g, lw, (char *)packed, (hipStream_t)stream);
+    if (g.cl_dir[1] != 0) return td_cluster_pack_all(cfg, g, lw, (char *)packed, (hipStream_t)stream);
     return TD_OK;
 }
 

@@ -7,6 +7,7 @@
 #define TDC_WAVES 4
 #define TDC_SPIN_LIMIT (1 << 22)
 #define TDC_CUS 256
+#define TDC_RESIDENT_MAX_NU 3   // widths of up to this many unit blocks: the whole layer in ONE workgroup (rnn_cluster.hip, td_rnn_resident_kernel)
 unsigned *td_async_error_word(bool create);   // api.cpp
 int td_cluster_device_cus(void);               // rnn_cluster.hip: compute units of the current device (cached), at most TDC_CUS
 // a poll gave up: every lane of the wave stores the same word (system scope: the word is host memory)

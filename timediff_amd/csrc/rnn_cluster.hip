@@ -129,9 +129,9 @@ __device__ __forceinline__ void td_cluster_unrolled(F &&f) {
     }
 }
 #define TDC_LDS_STATE_BLOCKS 16   // blocks per cluster whose recurrent state fits the LDS left beside the staging buffers
-template <int NF, int W0, int NW>
+template <int NF, int W0, int NW, int RING = TDC_RING>
 __device__ __forceinline__ void tdc_mfma_stream(f32x16 &acc, const bf16x8 (&W)[NW], const bf16x8 *src) {
-    constexpr int RD = NF < TDC_RING ? NF : TDC_RING;
+    constexpr int RD = NF < RING ? NF : RING;
     bf16x8 R[RD];
 #pragma unroll
     for (int i = 0; i < RD; ++i) R[i] = src[(size_t)i * 64];
@@ -149,7 +149,9 @@ __device__ __forceinline__ void tdc_mfma_stream(f32x16 &acc, const bf16x8 (&W)[N
 // h_t as activation fragment for the next layer, the saved gate values for the backward pass.
 // PAYLOAD (the kernel for several blocks per cluster): h_t leaves as untagged 8-byte stores into the parity's 16 KiB of
 // B-fragment-ordered payload at `xch` (the flag that covers it is raised by the caller behind a barrier).
-template <int NU, bool GRU, bool SAVE, bool PAYLOAD = false>
+// HAND: how h_t reaches the units' other owners.  0: tagged granule pairs (one block per cluster), 1: untagged payload
+// (several blocks per cluster), 2: `xch` is the LDS buffer of the next step (the whole layer width in ONE workgroup).
+template <int NU, bool GRU, bool SAVE, int HAND = 0>
 __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const f32x16 &acc, f32x4 &state, bool dead, float *cptr,
                                                 unsigned long long *xch, unsigned tag0, int s, int l, int bb, int dir, int c, int w,
                                                 int lane) {
@@ -188,6 +190,7 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
     typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
     bf16x4 hb = {(__bf16)hval[0], (__bf16)hval[1], (__bf16)hval[2], (__bf16)hval[3]};
     const unsigned long long hbits = *(const unsigned long long *)&hb;
+    constexpr bool PAYLOAD = HAND == 1;
     if constexpr (PAYLOAD) {
         // the payload goes out FIRST: the caller's counted wait lets the stores below stay in flight (TDC_STORES_BEHIND_PAYLOAD)
         if (s + 1 < p.L)
@@ -196,7 +199,9 @@ __device__ __forceinline__ void tdc_finish_step(const TdClusterParams &p, const 
         asm volatile("" ::: "memory");
     }
     if (cptr) *(f32x4 *)cptr = state;
-    if constexpr (PAYLOAD) {
+    if constexpr (HAND == 2) {
+        if (s + 1 < p.L) *(unsigned long long *)((char *)xch + (size_t)(2 * c + (w >> 1)) * TD_FRAG_BYTES + lane * 16 + 8 * (w & 1)) = hbits;
+    } else if constexpr (PAYLOAD) {
     } else if (s + 1 < p.L) {   // publish: two granules per lane, tag = (epoch, s + 1)
         const unsigned long long *dst = xch + (size_t)(s & 1) * (NU * TDC_WAVES * 128) + (size_t)(c * TDC_WAVES + w) * 128;
         const unsigned tag = tag0 | (unsigned)(s + 1);
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
             TDC_MARK(3)
             // gates, state, payload, outputs
             char *pay = region(bb) + (size_t)(s & 1) * KH * TD_FRAG_BYTES;
-            tdc_finish_step<NU, GRU, SAVE, true>(p, acc, state, dead, nblk > 1 && !st_lds && s + 1 < p.L ? cstp(bb) : nullptr,
+            tdc_finish_step<NU, GRU, SAVE, 1>(p, acc, state, dead, nblk > 1 && !st_lds && s + 1 < p.L ? cstp(bb) : nullptr,
                                                  (unsigned long long *)pay, tag0, s, l, bb, dir, c, w, lane);
             if (nblk == 1) keep = state;
             else if (st_lds) state_lds[j * 256 + tid] = state;
@@ -580,6 +585,103 @@ __global__ __launch_bounds__(256, 1) void td_rnn_cluster_multi_kernel(TdClusterP
                XF, (int)SAVE, it, cyc, (double)cyc / (double)rt * 100.0, stp[0] / it, stp[1] / it, stp[2] / it, stp[3] / it, stp[4] / it, stp[5] / it);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Widths of up to three unit blocks (H <= 96: the reference's default widths for MIMIC-III, 92, and HiRID, 36,
+// etdiff_train.py:239): the "cluster" is ONE workgroup of 4 NU waves on one CU.  The same decomposition -- wave (c, w)
+// owns the 8 units [32c + 8w, +8) with all their gates as one 32-row MFMA tile, its slice of [W_hh | W_ih] (at most 18
+// fragments = 72 registers) stays in registers for the whole sequence -- but h_t changes hands through LDS (double
+// buffered, one barrier per step) instead of through L2, so a step costs the CU's own MFMA and LDS time and no
+// round trip.  rnn_wide.hip, which these widths used before, streams the layer's weights from L2 every step (200 KiB at
+// H = 92: 3.9 us per step; here about a third of that).  One workgroup per (batch block, direction) and no hand-off
+// between workgroups: any batch runs, nothing needs to be co-resident.
+template <int NU, int XF, bool L0, bool GRU, bool SAVE>
+__global__ __launch_bounds__(256 * NU, 1) void td_rnn_resident_kernel(TdClusterParams p) {
+    constexpr int KH = 2 * NU, NFR = KH + XF, NW = TDC_WAVES * NU;
+    constexpr int XSTAGE = L0 ? 0 : XF;              // input fragments staged in LDS per step
+    constexpr int XLOAD = (XSTAGE + NW - 1) / NW;    // input fragments each wave brings in per step (the last round may be short)
+    constexpr int RING = NU == 3 ? 4 : TDC_RING;     // three waves per SIMD: 168 registers each
+    __shared__ __attribute__((aligned(16))) char lds[2 * KH * TD_FRAG_BYTES + 2 * (XSTAGE ? XSTAGE : 1) * TD_FRAG_BYTES];
+    char *hbuf = lds, *xbuf = lds + 2 * KH * TD_FRAG_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = wave >> 2, w = wave & 3;
+    const int dir = blockIdx.x % p.dirs, bb = blockIdx.x / p.dirs;
+
+    const char *wsl = p.wpacked + (size_t)dir * p.dir_stride + (size_t)wave * tdc_slice_bytes(NFR);
+    f32x16 bias;
+    {
+        const f32x4 *bp = (const f32x4 *)wsl + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = bp[q];
+            bias[4 * q] = v[0]; bias[4 * q + 1] = v[1]; bias[4 * q + 2] = v[2]; bias[4 * q + 3] = v[3];
+        }
+    }
+    bf16x8 W[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) W[f] = *((const bf16x8 *)(wsl + 4096 + (size_t)f * TD_FRAG_BYTES) + lane);
+
+    f32x4 state = {0.f, 0.f, 0.f, 0.f};      // LSTM: c; GRU: h (fp32) of units 32c + 8w + 4hf + i
+    auto xrow = [&](int l) { return p.xin + ((size_t)l * p.nbb + bb) * p.in_frags * TD_FRAG_BYTES; };
+    bf16x8 xpre[XLOAD ? XLOAD : 1];
+    auto x_issue = [&](int l) {
+        if constexpr (!L0) {
+            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
+#pragma unroll
+            for (int i = 0; i < XLOAD; ++i)
+                if (wave + NW * i < XSTAGE) xpre[i] = xp[(size_t)(wave + NW * i) * 64];
+        }
+    };
+    auto x_commit = [&](int par) {
+        if constexpr (!L0) {
+            bf16x8 *xd = (bf16x8 *)(xbuf + (size_t)par * XSTAGE * TD_FRAG_BYTES) + lane;
+#pragma unroll
+            for (int i = 0; i < XLOAD; ++i)
+                if (wave + NW * i < XSTAGE) xd[(size_t)(wave + NW * i) * 64] = xpre[i];
+        }
+    };
+    x_issue(dir ? p.L - 1 : 0);
+    x_commit(0);
+    // first layer: the few input fragments (hi / lo parts) go straight to registers, one step ahead
+    bf16x8 x0[L0 ? XF : 1];
+    auto x0_load = [&](int l) {
+        if constexpr (L0) {
+            const bf16x8 *xp = (const bf16x8 *)xrow(l) + lane;
+#pragma unroll
+            for (int f = 0; f < XF; ++f) x0[f] = xp[(size_t)f * 64];
+        }
+    };
+    x0_load(dir ? p.L - 1 : 0);
+
+    for (int s = 0; s < p.L; ++s) {
+        const int l = dir ? p.L - 1 - s : s;
+        __syncthreads();     // h_{s-1} and this step's inputs are in LDS; every wave is done with the other halves
+        if (s + 1 < p.L) x_issue(dir ? l - 1 : l + 1);
+        f32x16 acc = bias;
+        if constexpr (L0) {
+#pragma unroll
+            for (int kx = 0; kx < XF / 2; ++kx) {
+                const bf16x8 xh = x0[2 * kx], xl = x0[2 * kx + 1];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx + 1], xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[KH + 2 * kx], xh, acc, 0, 0, 0);
+            }
+            if (s + 1 < p.L) x0_load(dir ? l - 1 : l + 1);
+        } else {
+            const bf16x8 *xs = (const bf16x8 *)(xbuf + (size_t)(s & 1) * XSTAGE * TD_FRAG_BYTES) + lane;
+            tdc_mfma_stream<XF, KH, NFR, RING>(acc, W, xs);
+        }
+        if (s > 0) {
+            const bf16x8 *hs = (const bf16x8 *)(hbuf + (size_t)(s & 1) * KH * TD_FRAG_BYTES) + lane;
+            tdc_mfma_stream<KH, 0, NFR, RING>(acc, W, hs);
+        }
+        tdc_finish_step<NU, GRU, SAVE, 2>(p, acc, state, false, nullptr, (unsigned long long *)(hbuf + (size_t)((s + 1) & 1) * KH * TD_FRAG_BYTES),
+                                          0u, s, l, bb, dir, c, w, lane);
+        if (s + 1 < p.L) x_commit((s + 1) & 1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -617,6 +719,7 @@ size_t td_cluster_xch_dir_bytes(const TdRnnGeom &g, int nbb) {
 bool td_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
     // tags carry 12 bits of step index; a parity buffer must have been rewritten by this launch before a step index of the
     // previous launch can recur (L >= 4).  Any batch: a cluster works its batch blocks one after the other within a step.
+    if (g.nu <= TDC_RESIDENT_MAX_NU) return L >= 1 && nbb >= 1;      // one workgroup per (block, direction): nothing to co-schedule
     return g.nu == 8 && L >= 4 && L < 4096 && nbb >= 1 && td_cluster_device_cus() >= g.nu * g.dirs;
 }
 
@@ -665,6 +768,22 @@ static int tdc_launch2(int gru, int save, const TdClusterParams &p, int blocks, 
     return TD_OK;
 }
 
+template <int NU, int XF, bool L0>
+static int tdc_launch_resident(int gru, int save, const TdClusterParams &p, hipStream_t stream) {
+    const dim3 grid(p.nbb * p.dirs), block(256 * NU);
+    if (!gru && !save) hipLaunchKernelGGL((td_rnn_resident_kernel<NU, XF, L0, false, false>), grid, block, 0, stream, p);
+    else if (!gru) hipLaunchKernelGGL((td_rnn_resident_kernel<NU, XF, L0, false, true>), grid, block, 0, stream, p);
+    else if (!save) hipLaunchKernelGGL((td_rnn_resident_kernel<NU, XF, L0, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((td_rnn_resident_kernel<NU, XF, L0, true, true>), grid, block, 0, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+template <int NU>
+static int tdc_launch_resident_nu(int gru, int save, const TdRnnGeom &g, const TdClusterParams &p, bool layer0, hipStream_t stream) {
+    if (layer0) return g.kx0 == 1 ? tdc_launch_resident<NU, 2, true>(gru, save, p, stream) : tdc_launch_resident<NU, 4, true>(gru, save, p, stream);
+    return p.dirs == 1 ? tdc_launch_resident<NU, 2 * NU, false>(gru, save, p, stream) : tdc_launch_resident<NU, 4 * NU, false>(gru, save, p, stream);
+}
+
 // One layer, both directions.  `wcluster`: this layer's cluster-packed weights (direction 0), `dir_stride` to direction 1.
 int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayerParams &lp, const char *wcluster, size_t dir_stride,
                             bool layer0, unsigned long long *xch, hipStream_t stream) {
@@ -672,6 +791,12 @@ int td_launch_layer_cluster(int gru, int save, const TdRnnGeom &g, const TdLayer
     p.wpacked = wcluster; p.dir_stride = dir_stride;
     p.xin = lp.xin; p.out = lp.out; p.save = lp.save; p.save_dir_stride = lp.save_dir_stride;
     p.xch = xch; p.in_frags = lp.in_frags; p.out_frags = lp.out_frags; p.L = lp.L; p.nbb = lp.nbb; p.dirs = lp.dirs;
+    if (g.nu <= TDC_RESIDENT_MAX_NU) {      // the layer's whole width in one workgroup: no exchange buffer, no epoch
+        p.cstate = nullptr; p.ngroups = lp.nbb; p.epoch = 0; p.err = nullptr;
+        if (g.nu == 1) return tdc_launch_resident_nu<1>(gru, save, g, p, layer0, stream);
+        if (g.nu == 2) return tdc_launch_resident_nu<2>(gru, save, g, p, layer0, stream);
+        return tdc_launch_resident_nu<3>(gru, save, g, p, layer0, stream);
+    }
     // the state scratch follows the exchange buffers of both directions
     p.cstate = (float *)((char *)xch + (size_t)lp.dirs * lp.nbb * 2 * g.nu * TDC_WAVES * 128 * 8);
     // one workgroup per CU, every one resident at once: at most 256 / (NU * dirs) clusters per direction

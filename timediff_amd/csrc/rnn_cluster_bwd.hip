@@ -429,6 +429,161 @@ __global__ __launch_bounds__(256, 1) void td_bptt_cluster_kernel(TdClusterBwdPar
 }
 
 // ---------------------------------------------------------------------------------------------
+// Widths of up to three unit blocks (H <= 96): the sweep of one (batch block, direction) in ONE workgroup of 4 NU waves,
+// the counterpart of td_rnn_resident_kernel (rnn_cluster.hip).  W_hh^T (at most 72 KiB) stays in registers for the whole
+// sweep, split by (row block c', gate q): wave 4c' + q multiplies gate q's d a of ALL units (KH k-steps from LDS) into the
+// 32 x 32 partial sum of d h for the units of block c'.  The gate gradients are owned as in the forward kernel -- wave
+// 4c + w has the units [32c + 8w, +8), whose saved gate values it reads in the forward kernel's register order -- so the
+// partial sums change hands through LDS: wave 4c' + q writes its accumulator, wave 4c' + w adds up registers 4w .. 4w + 3
+// of the NT gates' accumulators.  Two barriers per step (d a complete / partial sums complete), nothing leaves the CU but
+// d a in the two layouts the GEMMs after the sweep read.  td_bptt_sweep_kernel, which these widths used before, reads
+// W_hh^T from L2 every step: 8 us per step at H = 92.
+template <int NU, bool GRU>
+__global__ __launch_bounds__(256 * NU, 1) void td_bptt_resident_kernel(TdClusterBwdParams p) {
+    constexpr int KH = 2 * NU, NT = GRU ? 3 : 4;
+    // [d a: 4 gates x KH fragments][partial sums: 4 NU waves x 4 KiB fp32]
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *dabuf = lds;
+    f32x4 *psum = (f32x4 *)(lds + 4 * KH * TD_FRAG_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = wave >> 2, w = wave & 3;          // as owner of gate gradients: units 32c + 8w + 4hf + i
+    const int dir = blockIdx.x % p.dirs, bb = blockIdx.x / p.dirs;
+    const bool mul = !GRU || w < NT;                // as multiplier: row block c, gate term w
+    const int slab = GRU ? (w == 2 ? 3 : w) : w;    // GRU: W_hn multiplies r * d a_n
+
+    bf16x8 W[KH];
+#pragma unroll
+    for (int f = 0; f < KH; ++f)
+        W[f] = mul ? *((const bf16x8 *)(p.wt + (size_t)dir * p.wt_dir + (((size_t)c * NT + (mul ? w : 0)) * KH + f) * TD_FRAG_BYTES) + lane) : bf16x8{};
+
+    const size_t cols = (size_t)p.L * p.nbb * 32;
+    constexpr int hpad = 32 * NU;
+    const size_t sub = (size_t)lane * 16 + 8 * (w & 1);
+    const int kfrag = 2 * c + (w >> 1);
+    auto lpos = [&](int s) { return dir ? s : p.L - 1 - s; };
+    auto save_at = [&](int l) {
+        return p.save + (size_t)dir * p.save_dir + ((((size_t)l * p.nbb + bb) * NU + c) * 5) * 1024 + lane * 16 + 4 * w;
+    };
+    f32x4 sv[5], pv;
+    unsigned long long gs[2];
+    auto prefetch = [&](int s) {
+        const int l = lpos(s);
+        const float *sp = save_at(l);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) sv[q] = *(const f32x4 *)(sp + q * 1024);
+        pv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s + 1 < p.L) pv = *(const f32x4 *)(save_at(dir ? l + 1 : l - 1) + 4 * 1024);   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+        const size_t go = (((size_t)l * p.nbb + bb) * p.out_frags + dir * KH + kfrag) * TD_FRAG_BYTES + sub;
+        gs[0] = *(const unsigned long long *)(p.gsrc[0] + go);
+        gs[1] = p.n_src > 1 ? *(const unsigned long long *)(p.gsrc[1] + go) : 0ull;
+    };
+    prefetch(0);
+
+    f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+    float dbacc[4][4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dbacc[gi][i] = 0.f;
+
+    for (int s = 0; s < p.L; ++s) {
+        const int l = lpos(s);
+        f32x4 dh;
+        {
+            const tdc_bf16x4 a = *(const tdc_bf16x4 *)&gs[0], b = *(const tdc_bf16x4 *)&gs[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dh[i] = (float)a[i] + (float)b[i];
+        }
+        if (s > 0) {      // registers 4w .. 4w + 3 of row block c's accumulators, one per gate term
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const f32x4 v = psum[((size_t)(c * 4 + q) * 4 + w) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dh[i] += v[i];
+            }
+        }
+        float da[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float g = dh[i], prev = pv[i];
+            if constexpr (!GRU) {
+                const float ig = sv[0][i], fg = sv[1][i], gg = sv[2][i], og = sv[3][i], cv = sv[4][i];
+                const float tc = td_tanh(cv);
+                const float dcv = carry[i] + g * (og * (1.0f - tc * tc));
+                da[0][i] = dcv * (gg * ig * (1.0f - ig));
+                da[1][i] = dcv * (prev * fg * (1.0f - fg));
+                da[2][i] = dcv * (ig * (1.0f - gg * gg));
+                da[3][i] = g * (tc * og * (1.0f - og));
+                carry[i] = dcv * fg;
+            } else {
+                const float rg = sv[0][i], zg = sv[1][i], ng = sv[2][i], hn = sv[3][i];
+                const float dht = g + carry[i];
+                const float an = (1.0f - zg) * (1.0f - ng * ng);
+                da[0][i] = dht * (an * hn * rg * (1.0f - rg));
+                da[1][i] = dht * ((prev - ng) * zg * (1.0f - zg));
+                da[2][i] = dht * an;
+                da[3][i] = dht * (an * rg);
+                carry[i] = dht * zg;
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dbacc[gi][i] += da[gi][i];
+        // d a_t: to LDS for the product (all units' fragments of a gate side by side), to HBM for the GEMMs after the sweep
+        {
+            char *fbase = p.daf + (size_t)dir * p.daf_dir + (((size_t)l * p.nbb + bb) * 4 * KH + kfrag) * TD_FRAG_BYTES + sub;
+            __bf16 *pl = p.dapl + (size_t)dir * p.dapl_dir + (size_t)(32 * c + 8 * w + 4 * hf) * cols + (size_t)l * p.nbb * 32 + bb * 32 + m;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const tdc_bf16x4 v = {(__bf16)da[gi][0], (__bf16)da[gi][1], (__bf16)da[gi][2], (__bf16)da[gi][3]};
+                const unsigned long long bits = *(const unsigned long long *)&v;
+                *(unsigned long long *)(dabuf + (size_t)(gi * KH + kfrag) * TD_FRAG_BYTES + sub) = bits;
+                *(unsigned long long *)(fbase + (size_t)gi * KH * TD_FRAG_BYTES) = bits;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pl[((size_t)gi * hpad + i) * cols] = v[i];
+            }
+        }
+        __syncthreads();     // d a_t of every unit is in LDS; every wave has read the partial sums of the step before
+        if (s + 1 < p.L) prefetch(s + 1);
+        if (s + 1 < p.L && mul) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const bf16x8 *bsrc = (const bf16x8 *)(dabuf + (size_t)slab * KH * TD_FRAG_BYTES) + lane;
+#pragma unroll
+            for (int f = 0; f < KH; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[f], bsrc[(size_t)f * 64], acc, 0, 0, 0);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                psum[((size_t)wave * 4 + g4) * 64 + lane] = f32x4{acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]};
+        }
+        __syncthreads();     // the partial sums are in LDS; every wave is done with d a_t
+    }
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = dbacc[gi][i];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            const int unit = 32 * c + 8 * w + 4 * hf + i;
+            if (m == 0 && unit < p.H) {
+                float *bi = p.db_ih[dir], *bh = p.db_hh[dir];
+                if (!GRU || gi < 2) {
+                    atomicAdd(&bi[gi * p.H + unit], t);
+                    atomicAdd(&bh[gi * p.H + unit], t);
+                } else if (gi == 2) {
+                    atomicAdd(&bi[2 * p.H + unit], t);
+                } else {
+                    atomicAdd(&bh[2 * p.H + unit], t);
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 #define TDC_BWD_MAX_BLOCKS 16     // batch blocks per cluster (their carries live in LDS: 4 KiB each)
@@ -439,6 +594,7 @@ static int tdc_bwd_groups(const TdRnnGeom &g, int nbb) {
 }
 
 bool td_bptt_cluster_supported(const TdRnnGeom &g, int nbb, int L) {
+    if (g.nu <= TDC_RESIDENT_MAX_NU) return L >= 1 && nbb >= 1;      // one workgroup per (block, direction)
     if (!(g.nu == TD_CLUSTER_NU && L >= 4 && L < 4096 && nbb >= 1 && td_cluster_device_cus() >= g.nu * g.dirs)) return false;
     return td_cdiv(nbb, tdc_bwd_groups(g, nbb)) <= TDC_BWD_MAX_BLOCKS;
 }
@@ -458,7 +614,22 @@ static int tdc_bwd_launch(const TdClusterBwdParams &p, int blocks, size_t shm, h
     return TD_OK;
 }
 
+template <int NU, bool GRU>
+static int tdc_bwd_launch_resident(const TdClusterBwdParams &p, hipStream_t stream) {
+    const size_t shm = (size_t)4 * 2 * NU * TD_FRAG_BYTES + (size_t)4 * NU * 4096;
+    TD_HIP(hipFuncSetAttribute((const void *)td_bptt_resident_kernel<NU, GRU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((td_bptt_resident_kernel<NU, GRU>), dim3(p.nbb * p.dirs), dim3(256 * NU), shm, stream, p);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
 int td_launch_bptt_cluster(int gru, const TdRnnGeom &g, TdClusterBwdParams &p, hipStream_t stream) {
+    if (g.nu <= TDC_RESIDENT_MAX_NU) {
+        p.ngroups = p.nbb; p.epoch = 0; p.err = nullptr;
+        if (g.nu == 1) return gru ? tdc_bwd_launch_resident<1, true>(p, stream) : tdc_bwd_launch_resident<1, false>(p, stream);
+        if (g.nu == 2) return gru ? tdc_bwd_launch_resident<2, true>(p, stream) : tdc_bwd_launch_resident<2, false>(p, stream);
+        return gru ? tdc_bwd_launch_resident<3, true>(p, stream) : tdc_bwd_launch_resident<3, false>(p, stream);
+    }
     if (!td_bptt_cluster_supported(g, p.nbb, p.L)) {
         td_set_error("cluster BPTT kernel: %d unit blocks x %d directions x %d batch blocks, L = %d is outside its range", g.nu, g.dirs,
                      p.nbb, p.L);

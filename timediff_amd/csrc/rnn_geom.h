@@ -44,7 +44,7 @@ static inline int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
         off += (l == 0 ? g->g0.dir_bytes : g->g1.dir_bytes) * cfg->dirs;
     }
     g->cl_dir[0] = g->cl_dir[1] = 0;
-    if (nu == TD_CLUSTER_NU) {
+    if (nu == TD_CLUSTER_NU || nu <= 3) {      // (nu <= 3: the one-workgroup form of the same kernel, TDC_RESIDENT_MAX_NU)
         // per (unit slice c, wave): 4 KiB of bias registers + one 1 KiB fragment per k-step (rnn_cluster.hip)
         g->cl_dir[0] = (size_t)nu * 4 * (4096 + (size_t)(g->kh + 2 * kx0) * 1024);
         g->cl_dir[1] = (size_t)nu * 4 * (4096 + (size_t)(g->kh + cfg->dirs * g->kh) * 1024);
