@@ -1233,8 +1233,13 @@ struct TdDwParams {
     const __bf16 *A, *B;     // row-major, k contiguous
     float *C;
     size_t lda, ldb;
-    int ldc, M, N, K;        // M valid rows of A, N rows of B (a multiple of 32)
+    int ldc, M, N, K;        // M rows of A, N rows of B (a multiple of 32)
     int hp, hv;              // column map: n -> (n / hp) * hv + n % hp, valid when n % hp < hv
+    // row map: row m of the product is row m % mp of the slab a_slab[m / mp] (elements from A) and goes to row
+    // (m / mp) * mv + m % mp of C, valid when m % mp < mv: the gates' slabs of d a (padded to whole unit blocks, and for the
+    // GRU's W_hh not adjacent) in ONE product.  mp = mv = M, a_slab[0] = 0: no map.
+    int mp, mv;
+    size_t a_slab[4];
     int kc, nsplit;          // columns per chunk (a multiple of TD_DW_BK), chunks
     float *partial;          // nsplit > 1: [chunk][M][N] fp32
 };
@@ -1256,13 +1261,22 @@ __global__ __launch_bounds__(256, 1) void td_dw_gemm_kernel(TdDwParams p) {
     const int c = tid & 7, row0 = tid >> 3;
     const __bf16 *ag = p.A + (size_t)(m0 + row0) * p.lda + c * 8, *bg = p.B + (size_t)(n0 + row0) * p.ldb + c * 8;
     const size_t astep = (size_t)32 * p.lda, bstep = (size_t)32 * p.ldb;
+    // EDGE: this thread's rows of A through the row map (a row beyond M or in a slab's padding reads as zero)
+    const __bf16 *arow[EDGE ? NLA : 1];
+    if constexpr (EDGE) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            arow[i] = (m < p.M && m % p.mp < p.mv) ? p.A + p.a_slab[m / p.mp] + (size_t)(m % p.mp) * p.lda + c * 8 : nullptr;
+        }
+    }
     bf16x8 va[NLA], vb[NLB];
     auto gload = [&](int k) {
         if constexpr (EDGE) {
             const bool inside = k + c * 8 < k1;      // K is a multiple of 8: a piece is wholly inside or outside
             const bf16x8 zero = {};
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) va[i] = (inside && m0 + row0 + 32 * i < p.M) ? *(const bf16x8 *)(ag + i * astep + k) : zero;
+            for (int i = 0; i < NLA; ++i) va[i] = (inside && arow[i]) ? *(const bf16x8 *)(arow[i] + k) : zero;
 #pragma unroll
             for (int i = 0; i < NLB; ++i) vb[i] = (inside && n0 + row0 + 32 * i < p.N) ? *(const bf16x8 *)(bg + i * bstep + k) : zero;
         } else {
@@ -1323,50 +1337,66 @@ __global__ __launch_bounds__(256, 1) void td_dw_gemm_kernel(TdDwParams p) {
         __syncthreads();     // the other buffer is complete, and every wave is done with this one
         buf ^= 1;
     }
-    // accumulator element q of lane (r, hf): row (q & 3) + 8 (q >> 2) + 4 hf, column r of its 32 x 32 tile
+    // accumulator element q of lane (r, hf): row (q & 3) + 8 (q >> 2) + 4 hf, column r of its 32 x 32 tile.  A slab of the row
+    // map is a whole number of 32-row tiles (or the map is the identity), so a tile's rows share one slab: one division a tile.
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i) {
+        const int mb = m0 + (wm * WM + i) * 32;
+        const int rb = mb % p.mp + 4 * hf;              // row within the slab of accumulator element 0
+        const size_t crow0 = (size_t)(mb / p.mp) * p.mv + rb;
+        const int mlim = min(p.M - mb - 4 * hf, p.mv - rb);   // element q is valid while (q & 3) + 8 (q >> 2) is below this
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + (wn * WN + j) * 32 + r;
             if (n >= p.N) continue;
             if (p.nsplit > 1) {
-                float *dst = p.partial + (size_t)split * p.M * p.N + n;
+                float *dst = p.partial + (size_t)split * p.M * p.N + (size_t)(mb + 4 * hf) * p.N + n;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
-                    if (m < p.M) dst[(size_t)m * p.N] = acc[i][j][q];
+                    const int dm = (q & 3) + 8 * (q >> 2);
+                    if (dm < p.M - mb - 4 * hf) dst[(size_t)dm * p.N] = acc[i][j][q];
                 }
             } else if (n % p.hp < p.hv) {
-                const int col = (n / p.hp) * p.hv + n % p.hp;
+                float *dst = p.C + crow0 * p.ldc + (n / p.hp) * p.hv + n % p.hp;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
-                    if (m < p.M) p.C[(size_t)m * p.ldc + col] += acc[i][j][q];     // this workgroup owns the tile
+                    const int dm = (q & 3) + 8 * (q >> 2);
+                    if (dm < mlim) dst[(size_t)dm * p.ldc] += acc[i][j][q];     // this workgroup owns the tile
                 }
             }
         }
+    }
 }
 
 // C[m][col(n)] += sum over the chunks' slabs (each M x N, packed), in chunk order
 __global__ __launch_bounds__(256) void td_dw_reduce_kernel(TdDwParams p) {
     const size_t total = (size_t)p.M * p.N;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int n = (int)(i % p.N);
-        if (n % p.hp >= p.hv) continue;
+        const int n = (int)(i % p.N), m = (int)(i / p.N);
+        if (n % p.hp >= p.hv || m % p.mp >= p.mv) continue;
         float s = 0.f;
         for (int k = 0; k < p.nsplit; ++k) s += p.partial[(size_t)k * total + i];
-        p.C[(i / p.N) * p.ldc + (n / p.hp) * p.hv + n % p.hp] += s;
+        p.C[(size_t)((m / p.mp) * p.mv + m % p.mp) * p.ldc + (n / p.hp) * p.hv + n % p.hp] += s;
     }
 }
 
 // Chunks of K: enough of them that tiles x chunks cover the chip, each at least TD_DW_MIN_KC columns, all slabs within the
 // workspace's TD_DW_PARTIAL_BYTES.  Tile: 256 x 256 (a wave 128 x 128: 8 fragment reads feed 16 matrix instructions);
 // 256 x 64 where B has few rows (the first layer's input channels).
+// Small products (the narrow widths: a few hundred rows and columns): 128 x 128 tiles, so that tiles x chunks still cover
+// the chip and a workgroup does not multiply a mostly empty 256 x 256 tile (37 us per call at H = 92 that way).
 #define TD_DW_MIN_KC 512
 static int td_dw_gemm(TdDwParams q, float *partial, hipStream_t stream) {
+    // unpadded, adjacent slabs are plain rows: no map (and with it the unpredicated kernels where the shape allows them)
+    bool plain_rows = q.mv == q.mp;
+    for (int gi = 0; gi < q.M / q.mp && plain_rows; ++gi) plain_rows = q.a_slab[gi] == (size_t)gi * q.mp * q.lda;
+    if (plain_rows) {
+        q.mp = q.mv = q.M;
+        q.a_slab[0] = 0;
+    }
     const bool narrow = q.N <= 64;
-    const int bm = 256, bn = narrow ? 64 : 256;
+    const bool small = !narrow && q.M <= 512 && q.N <= 512;
+    const int bm = small ? 128 : 256, bn = narrow ? 64 : (small ? 128 : 256);
     const int tm = td_cdiv(q.M, bm), tn = td_cdiv(q.N, bn);
     int ns = 1;
     while (partial && ns < 128 && tm * tn * ns < 256 && q.K / (2 * ns) >= TD_DW_MIN_KC &&
@@ -1376,9 +1406,10 @@ static int td_dw_gemm(TdDwParams q, float *partial, hipStream_t stream) {
     q.nsplit = td_cdiv(q.K, q.kc);
     q.partial = partial;
     TD_REQUIRE(q.K % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0, "weight-gradient GEMM: K and the leading dimensions must be multiples of 8");
-    const bool edge = q.M % bm != 0 || q.N % bn != 0 || q.K % TD_DW_BK != 0;   // a short last chunk is whole stages still
+    const bool edge = q.M % bm != 0 || q.N % bn != 0 || q.K % TD_DW_BK != 0 || q.mp != q.M;   // a short last chunk is whole stages still
     const dim3 grid(tm, tn, q.nsplit);
-    if (narrow && edge) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 1, true>), grid, dim3(256), 0, stream, q);
+    if (small) hipLaunchKernelGGL((td_dw_gemm_kernel<2, 2, true>), grid, dim3(256), 0, stream, q);
+    else if (narrow && edge) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 1, true>), grid, dim3(256), 0, stream, q);
     else if (narrow) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 1, false>), grid, dim3(256), 0, stream, q);
     else if (edge) hipLaunchKernelGGL((td_dw_gemm_kernel<4, 4, true>), grid, dim3(256), 0, stream, q);
     else hipLaunchKernelGGL((td_dw_gemm_kernel<4, 4, false>), grid, dim3(256), 0, stream, q);
@@ -1496,13 +1527,17 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
             // LSTM with an unpadded width: the four gates' slabs of d a and their rows of d W are contiguous, so all
             // gates go in one GEMM / one bias reduction per tensor (GM = 4 gates per call)
             const int GM = (!cfg->gru && g.hpad == H) ? G : 1;
-            for (int gate = 0; gate < G; gate += GM) {
-                const int slab_x = gate, slab_h = (cfg->gru && gate == 2) ? 3 : gate;
+            {
+                // every gate in ONE product per tensor: the gates' slabs of d a (hpad rows each, H of them valid; for the GRU's
+                // W_hh the slabs r, z, r * n) are the row blocks of A, mapped to the gates' rows of d W
                 TdDwParams q;
+                q.M = G * g.hpad; q.mp = g.hpad; q.mv = H;
+                for (int gate = 0; gate < G; ++gate) q.a_slab[gate] = (size_t)gate * t.dapl_slab_elems;
+                q.a_slab[3] = G == 4 ? q.a_slab[3] : 0;
                 // W_ih
-                q.A = dapl + (size_t)slab_x * t.dapl_slab_elems; q.lda = t.cols;
+                q.A = dapl; q.lda = t.cols;
                 q.B = (const __bf16 *)(ws + t.plainx[l]); q.ldb = t.cols;     // this layer's input (the dropped copy, with dropout)
-                q.C = gw[0] + (size_t)gate * H * In; q.ldc = In; q.M = GM * H; q.K = (int)t.cols;
+                q.C = gw[0]; q.ldc = In; q.K = (int)t.cols;
                 if (l == 0) { q.N = t.cpad; q.hp = t.cpad; q.hv = cfg->c_in; }
                 else { q.N = D * g.hpad; q.hp = g.hpad; q.hv = H; }
                 rc = td_dw_gemm(q, dwpart, stream);
@@ -1510,14 +1545,17 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 // W_hh: h_{t-1} is this direction's own output one step earlier in its processing order
                 if (L > 1) {
                     const __bf16 *hpl = (const __bf16 *)(ws + t.plain[l + 1]) + (size_t)d * g.hpad * t.cols;
-                    const __bf16 *da_h = dapl + (size_t)slab_h * t.dapl_slab_elems;
-                    q.A = d == 0 ? da_h + t.Bp : da_h;
+                    if (cfg->gru) q.a_slab[2] = (size_t)3 * t.dapl_slab_elems;
+                    q.A = d == 0 ? dapl + t.Bp : dapl;
                     q.B = d == 0 ? hpl : hpl + t.Bp;
-                    q.C = gw[1] + (size_t)gate * H * H; q.ldc = H; q.K = (int)(t.cols - t.Bp);
+                    q.C = gw[1]; q.ldc = H; q.K = (int)(t.cols - t.Bp);
                     q.N = g.hpad; q.hp = g.hpad; q.hv = H;
                     rc = td_dw_gemm(q, dwpart, stream);
                     if (rc != TD_OK) return rc;
                 }
+            }
+            for (int gate = 0; gate < G; gate += GM) {
+                const int slab_x = gate, slab_h = (cfg->gru && gate == 2) ? 3 : gate;
                 // biases (hidden sizes up to 256: folded into the sweep)
                 if (g.nu <= 8) continue;
                 hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(GM * H, 4)), dim3(256), 0, stream,
