@@ -2,7 +2,7 @@
 """Sampler and training rates at the shapes of BASELINE.json's configs other than the headline one (which bench.py
 measures): MIMIC-III-shaped (configs[0]) and HiRID-shaped at the reference's own width, on one MI355X.
     python3 tools/config_bench.py            -> one JSON line per shape
-Sampler: a T = 16 chain timed and scaled to the reference's T = 1000 (the per-step cost does not depend on t)."""
+Sampler: a T = 64 chain timed and scaled to the reference's T = 1000 (the per-step cost does not depend on t)."""
 import json
 import os
 import sys
@@ -25,7 +25,7 @@ def main():
     from timediff_amd.ops import DenoiserKernels, DiffusionKernels, SamplerKernels
     from timediff_amd.schedule import make_tables
     dev = torch.device("cuda:0")
-    T, N, D = 16, 3, 2
+    T, N, D = 64, 3, 2
     for name, (cols, L, H) in SHAPES.items():
         C_io = len(cols["num"]) + sum(cols["K"])
         C = len(cols["num"]) + len(cols["cat"])
