@@ -397,17 +397,20 @@ def main():
         # HBM traffic of that kernel per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); bench.py cannot collect counters itself, so it
         # reports the committed measurement when it was taken at this batch size
-        traffic = None
+        # (the probe's launches are the PLAIN variant of the upper-layer kernel: the tensor-level forward keeps the head as
+        # its own kernel; the chain's top layer is the HEAD variant, its first layer the L0 variant: all three are in the file)
+        traffic, variants = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "layer_kernel_pmc.json")) as f:
                 pm = json.load(f)
             if pm.get("batch") == B and pm.get("seq_len") == L and pm.get("hidden") == H:
-                traffic = pm["hbm_bytes_per_launch"]
+                traffic = pm["variants"]["plain"]["hbm_bytes_per_launch"]
+                variants = {k: dict(hbm_bytes_per_launch=v["hbm_bytes_per_launch"], mfma_util=v["mfma_util"]) for k, v in pm["variants"].items()}
         except (OSError, ValueError, KeyError):
             pass
-        roofline = dict(bound="mfma", kernel="td_rnn_layer_kernel<NU=8,KX=32,L0=0,GRU=0>", achieved=achieved,
-                        peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK_TFLOPS,
-                        traffic=traffic, traffic_unit="bytes per launch (PMC)", launches_timed=cnt.value,
+        roofline = dict(bound="mfma", kernel="td_rnn_layer_kernel<NU=8,KX=32,L0=0,GRU=0,SAVE=0,HEAD=0>", variant="plain",
+                        achieved=achieved, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK_TFLOPS,
+                        traffic=traffic, traffic_unit="bytes per launch (PMC)", pmc_by_variant=variants, launches_timed=cnt.value,
                         avg_launch_ms=avg_s * 1e3, flops_per_launch=flops_launch)
         note(f"roofline probe: {cnt.value} launches, {avg_s * 1e3:.2f} ms each")
         base = None

@@ -19,7 +19,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'td_' in k: agg[k.split('(')[0][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'td_' in k: agg[k.split('(')[0][:100]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(agg):
     print(k)
     for c in sorted(agg[k]): print(f"    {c:32s} {sum(agg[k][c])/len(agg[k][c]):.5g}  (n={len(agg[k][c])})")
