@@ -341,8 +341,8 @@ TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch, i
 enum { TD_HEAD_FUSION_AUTO = 0, TD_HEAD_FUSION_OFF = 1, TD_HEAD_FUSION_ON = 2 };
 TD_API int td_set_head_fusion(int32_t mode);
 
-/* No counterpart in the reference.  The cluster-persistent kernels (small batches at hidden 193..256) need every workgroup
- * of a launch resident at once.  Where the device cannot give that (shared with another process, CU mask) a bounded poll
+/* No counterpart in the reference.  The cluster-persistent kernels (small batches at hidden 193..256; the one-workgroup form
+ * at hidden <= 96 has no hand-off between workgroups and cannot raise this) need every workgroup of a launch resident at once.  Where the device cannot give that (shared with another process, CU mask) a bounded poll
  * inside the kernel times out: the outputs are poisoned with NaN and a word in device-writable host memory is raised.
  * This call reads and clears that word without touching the GPU: TD_OK, or TD_ERR_HIP with a message.  Call it wherever
  * the results of enqueued work have been waited for (the Python layer does, after it reads a loss or copies samples). */
