@@ -133,6 +133,23 @@ def test_resident_family_forced(nu, gru, shape, dev, knob):
     _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
 
 
+@pytest.mark.parametrize("H,Cc,n_num,L,gru", [(92, 23, 7, 24, 0), (36, 9, 7, 100, 0), (36, 9, 7, 100, 1)])
+def test_resident_kernels_at_the_reference_shapes(H, Cc, n_num, L, gru, dev):
+    """The reference's default widths and lengths (etdiff_train.py:24-29, :239: MIMIC-III H = 92, L = 24; HiRID H = 36,
+    L = 100) at batch 256 under AUTO: the one-workgroup kernels, forward and BPTT over the whole sequence length (99
+    hand-overs of h / partial sums through LDS), oracle on a subset of the sequences."""
+    from timediff_amd import _lib
+    B = 256
+    sd = random_state(H, Cc, 3, 2, gru, seed=H + L)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_CLUSTER
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=L)
+    rows = np.unique(np.concatenate([np.arange(0, 34), np.arange(0, B, 29), np.arange(B - 20, B)]))
+    gy = np.zeros((B, Cc, L), np.float32)
+    gy[rows] = (rng.standard_normal((len(rows), Cc, L)) / (len(rows) * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, rows, dev)
+
+
 # (H, gru, dirs, B): just above the automatic switch to the batch-block kernel
 AUTO_CASES = [
     (256, 0, 2, 8192 + 40),     # bench.py's configuration (BASELINE.json configs[1]/[2]): <8, 1, L0> and <8, 32, upper>
