@@ -258,6 +258,8 @@ struct TdRevParams {
     float *z;
     uint8_t *idx;
     const int32_t *t_dev;
+    int32_t *t_next;          // NULL, or where one thread leaves t - 1 for the NEXT step's kernels (the sampler's chain alternates
+                              // between two words, so no kernel of this step reads the one written here)
     const float *noise, *uniforms;
     size_t noise_stride, uni_stride;
     td_rng rng;
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256, TD_REV_WAVES) void td_reverse_step_kernel(TdRe
     const int L = c.seq_len, C_io = c.n_num + p.sumk, T = c.timesteps, LQ = L / VEC;
     const int t = p.t_dev ? p.t_dev[0] : p.t_host;
     if (t < 0 || t >= T) return;
+    if (p.t_next && blockIdx.x == 0 && threadIdx.x == 0) p.t_next[0] = t - 1;
     const float *noise = p.noise, *uniforms = p.uniforms;
     // chained external draws: slab 0 is the prior, slab T - t belongs to step t
     if (noise && p.noise_stride) noise += (size_t)(T - t) * p.noise_stride;
@@ -428,10 +431,11 @@ static int td_launch_reverse(const TdRevParams &p, hipStream_t stream) {
 }
 
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
-                           const int32_t *t_dev, const float *noise, const float *uniforms, size_t noise_stride,
+                           const int32_t *t_dev, int32_t *t_next, const float *noise, const float *uniforms, size_t noise_stride,
                            size_t uni_stride, td_rng rng, hipStream_t stream) {
     TdRevParams p;
     p.c = *cfg; p.B = batch; p.sumk = td_sum_k(cfg); p.t_host = t_host; p.mo = mo; p.z = z; p.idx = idx; p.t_dev = t_dev;
+    p.t_next = t_next;
     p.noise = noise; p.uniforms = uniforms; p.noise_stride = noise_stride; p.uni_stride = uni_stride; p.rng = rng;
     p.x0_out = p.mean_out = p.log_theta_out = nullptr;
     return td_launch_reverse<false>(p, stream);
@@ -444,7 +448,7 @@ extern "C" int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t bat
     if (rc != TD_OK) return rc;
     TD_REQUIRE(model_out && (z || cfg->n_num == 0) && (idx || cfg->n_cat == 0), "NULL argument");
     TD_REQUIRE(t_dev || (t_host >= 0 && t_host < cfg->timesteps), "t = %d outside [0, %d)", t_host, cfg->timesteps);
-    return td_launch_reverse_step(cfg, batch, model_out, z, idx, t_host, t_dev, noise, uniforms, 0, 0, rng,
+    return td_launch_reverse_step(cfg, batch, model_out, z, idx, t_host, t_dev, nullptr, noise, uniforms, 0, 0, rng,
                                   (hipStream_t)stream);
 }
 
@@ -457,7 +461,7 @@ extern "C" int td_reverse_step_terms(const td_diffusion_config *cfg, int32_t bat
     TD_REQUIRE(t >= 0 && t < cfg->timesteps, "t = %d outside [0, %d)", t, cfg->timesteps);
     TdRevParams p;
     p.c = *cfg; p.B = batch; p.sumk = td_sum_k(cfg); p.t_host = t; p.mo = model_out; p.z = (float *)z; p.idx = (uint8_t *)idx;
-    p.t_dev = nullptr; p.noise = nullptr; p.uniforms = nullptr; p.noise_stride = 0; p.uni_stride = 0;
+    p.t_dev = nullptr; p.t_next = nullptr; p.noise = nullptr; p.uniforms = nullptr; p.noise_stride = 0; p.uni_stride = 0;
     p.rng.seed = 0; p.rng.patient0 = 0; p.rng.tag = 0; p.rng.seed_dev = nullptr;
     p.x0_out = x0; p.mean_out = mean; p.log_theta_out = log_theta;
     return td_launch_reverse<true>(p, (hipStream_t)stream);

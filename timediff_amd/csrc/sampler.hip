@@ -1,7 +1,9 @@
 // The T-step reverse chain (mixed_diffusion.py:425-454, gaussian_diffusion.py:133-152) as a replayed
 // hipGraph: one captured step = {denoiser input + layer-0 packing, recurrent layers, head, reverse
-// update, step counter decrement}; every kernel reads the step index from a device counter, so the
-// same executable graph (8 steps) is replayed T / 8 times with no host round trip in between.
+// update}; every kernel reads the step index from a device word, so the same executable graph (8 steps) is replayed
+// T / 8 times with no host round trip in between.  Two words, used alternately: step j's kernels read word j & 1, and
+// its reverse-update kernel leaves t - 1 in the other word for step j + 1 (a separate decrement launch per step was a
+// kernel boundary of its own: 3 % of a reverse step at the MIMIC-III shape).
 #include "common.h"
 
 #include <string.h>
@@ -10,11 +12,10 @@ int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *co
                    const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, const float *film, int film_rows,
                    const int32_t *film_row, int batch, int L, float *y, void *workspace, hipStream_t stream, bool chain);
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
-                           const int32_t *t_dev, const float *noise, const float *uniforms, size_t noise_stride,
+                           const int32_t *t_dev, int32_t *t_next, const float *noise, const float *uniforms, size_t noise_stride,
                            size_t uni_stride, td_rng rng, hipStream_t stream);
 
 __global__ void td_set_counter_kernel(int32_t *p, int32_t v) { p[0] = v; }
-__global__ void td_dec_counter_kernel(int32_t *p) { p[0] -= 1; }
 
 #define TD_STEPS_PER_GRAPH 8
 
@@ -98,18 +99,15 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
     hipLaunchKernelGGL(td_set_counter_kernel, dim3(1), dim3(1), 0, stream, counter, T - 1);
     TD_LAUNCH_CHECK();
 
-    auto enqueue_step = [&]() -> int {
+    auto enqueue_step = [&](int j) -> int {
         int r;
+        int32_t *t_now = counter + (j & 1), *t_next = counter + ((j + 1) & 1);
         // denoiser input (mixed_diffusion.py:439) and its layer-0 fragment packing in one pass, the layers, the head
         // (fused into the top layer's kernel where the batch-block family runs it)
-        r = td_rnn_denoise(rnn, packed, misc, nullptr, cfg, z, idx, film_table, T, counter, batch, L, mo, rnn_ws, stream, true);
+        r = td_rnn_denoise(rnn, packed, misc, nullptr, cfg, z, idx, film_table, T, t_now, batch, L, mo, rnn_ws, stream, true);
         if (r != TD_OK) return r;
-        r = td_launch_reverse_step(cfg, batch, mo, z, idx, 0, counter, noise, uniforms, noise ? nstride : 0,
-                                   uniforms ? ustride : 0, rng, stream);
-        if (r != TD_OK) return r;
-        hipLaunchKernelGGL(td_dec_counter_kernel, dim3(1), dim3(1), 0, stream, counter);
-        TD_LAUNCH_CHECK();
-        return TD_OK;
+        return td_launch_reverse_step(cfg, batch, mo, z, idx, 0, t_now, t_next, noise, uniforms, noise ? nstride : 0,
+                                      uniforms ? ustride : 0, rng, stream);
     };
 
     // One graph launch carries several steps: a launch costs the GPU an idle gap of the order of a millisecond
@@ -132,7 +130,7 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
             td_sample_chain_release();
             hipGraph_t graph = nullptr;
             TD_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            for (int k = 0; k < steps_per_graph && rc == TD_OK; ++k) rc = enqueue_step();
+            for (int k = 0; k < steps_per_graph && rc == TD_OK; ++k) rc = enqueue_step(k);     // an even number of steps: a replay starts at word 0 again
             hipError_t e = hipStreamEndCapture(stream, &graph);
             if (rc != TD_OK) {
                 if (graph) (void)hipGraphDestroy(graph);
@@ -152,12 +150,12 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
         // captured block + the remainder enqueued directly
         for (int s = 0; s < T / steps_per_graph; ++s) TD_HIP(hipGraphLaunch(g_chain.exec, stream));
         for (int s = 0; s < T % steps_per_graph; ++s) {
-            rc = enqueue_step();
+            rc = enqueue_step(s);
             if (rc != TD_OK) return rc;
         }
     } else {
         for (int s = 0; s < T; ++s) {
-            rc = enqueue_step();
+            rc = enqueue_step(s);
             if (rc != TD_OK) return rc;
         }
     }
