@@ -425,7 +425,7 @@ def main():
             torch.cuda.empty_cache()
             train = {"reference_batch": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 5),
                      "reference_batch_looped": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 5, fuse=False),
-                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 12, 2)}
+                     "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 12, 4)}      # (warm-up > ETDiff.graph_warmup: the capture is not timed)
         fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
         result = {
             "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,
