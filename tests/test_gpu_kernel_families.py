@@ -441,3 +441,33 @@ def test_cluster_handoff_repeatable_under_load(dev, knob):
         assert torch.equal(y, ref_y), f"forward differs in repetition {rep}"
         for k in keys:
             assert torch.equal(got[k], ref_g[k]), f"the gradient of {k} differs in repetition {rep}"
+
+
+def test_side_stream_weight_gradients_equal_inline(dev):
+    """td_rnn_backward runs a layer's weight-gradient GEMMs on the library's side stream beside the sweeps below (small
+    batches); td_set_side_gemm(0) keeps them on the caller's stream.  Same kernels, same fixed summation order: the weight
+    gradients are bit-identical, three times in a row (a missing fork or join would race with the sweeps / the read-back)."""
+    from timediff_amd import _lib
+    B, L, Cc, n_num = 64, 40, 14, 4
+    sd = random_state(256, Cc, 3, 2, 0, seed=12)
+    den = den_kernels(sd, dev)
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=13)
+    gy = (rng.standard_normal((B, Cc, L)) / (B * L)).astype(np.float32)
+    film = den.time_film(cu(t, dev))
+    keys = [k for k in den._lkeys if "weight" in k and not k.endswith("ih_l0") and not k.endswith("ih_l0_reverse")]
+    got = {}
+    try:
+        for on in (1, 0, 1, 0, 1):
+            _lib.check(_lib.lib().td_set_side_gemm(on))
+            den.forward_train(cu(x, dev), film)
+            g_layer, _, _ = den.backward(cu(gy, dev), film)
+            cur = {k: g.clone() for k, g in zip(den._lkeys, g_layer) if k in keys}
+            torch.cuda.synchronize()
+            if not got:
+                got = cur
+                assert all(torch.isfinite(v).all() and v.abs().max() > 0 for v in got.values())
+            else:
+                for k in keys:
+                    assert torch.equal(cur[k], got[k]), (k, on)
+    finally:
+        _lib.lib().td_set_side_gemm(1)

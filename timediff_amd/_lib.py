@@ -103,6 +103,7 @@ _SIGS = {
     "td_cls_forward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "td_cls_backward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(_P), _P, _P, _P]),
     "td_set_head_fusion": (C.c_int, [_I]),
+    "td_set_side_gemm": (C.c_int, [_I]),
     "td_check_async_errors": (C.c_int, []),
     "td_profile_enable": (C.c_int, [_I]),
     "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
@@ -129,6 +130,8 @@ def lib():
         mode = os.environ.get("TIMEDIFF_LAYER_KERNEL", "")
         if mode[:1] in ("b", "u", "c"):
             handle.td_set_layer_kernel({"b": LAYER_KERNEL_BATCH, "u": LAYER_KERNEL_UNITS, "c": LAYER_KERNEL_CLUSTER}[mode[0]])
+        if os.environ.get("TIMEDIFF_SIDE_GEMM", "") == "0":
+            handle.td_set_side_gemm(0)
     return _lib
 
 

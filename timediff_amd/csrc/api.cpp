@@ -33,6 +33,13 @@ extern "C" int td_set_head_fusion(int32_t mode) {
     return TD_OK;
 }
 
+static int g_side_gemm = 1;
+int td_side_gemm_mode(void) { return g_side_gemm; }
+extern "C" int td_set_side_gemm(int32_t on) {
+    g_side_gemm = on ? 1 : 0;
+    return TD_OK;
+}
+
 extern "C" int td_set_layer_kernel(int32_t mode) {
     if (mode != TD_LAYER_KERNEL_AUTO && mode != TD_LAYER_KERNEL_BATCH && mode != TD_LAYER_KERNEL_UNITS && mode != TD_LAYER_KERNEL_CLUSTER) {
         td_set_error("td_set_layer_kernel: unknown mode %d", mode);
