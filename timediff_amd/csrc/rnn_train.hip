@@ -1448,14 +1448,14 @@ __global__ __launch_bounds__(256) void td_bias_reduce_kernel(const __bf16 *A, si
 // A second stream of the library's own for the weight-gradient GEMMs.  At the reference's batch the BPTT sweep of a layer keeps
 // 32 of the 256 CUs busy for 0.8 ms; the GEMMs of the layer above (which read only that layer's d a and the activations the
 // forward pass saved) need nothing from it and nothing needs them before the optimizer step, so they run beside it: forked
-// behind an event after the layer's sweep, joined at the end of the backward pass.  One stream and NL + 1 events per device,
+// behind an event after the layer's sweep, joined at the end of the backward pass.  One stream and 18 events per device,
 // created at the first use (the same fork / join is captured as such when the caller's stream is under graph capture).
 #ifndef TD_SIDE_GEMM_MAX_CUS
 #define TD_SIDE_GEMM_MAX_CUS 64     // CUs a sweep occupies (measured at H = 256: 32 CUs +3.7 %, 128 CUs -7 %)
 #endif
 struct TdSideStream {
     hipStream_t stream;
-    hipEvent_t fork[16], join;
+    hipEvent_t fork[17], join;      // one per layer + the head
     bool ready;
 };
 static TdSideStream *td_side_stream(void) {
@@ -1465,7 +1465,7 @@ static TdSideStream *td_side_stream(void) {
     TdSideStream &s = side[dev];
     if (!s.ready) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < 17; ++i)
             if (hipEventCreateWithFlags(&s.fork[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
         s.ready = true;
@@ -1476,17 +1476,24 @@ static TdSideStream *td_side_stream(void) {
 // ---------------------------------------------------------------------------------------------
 // The recurrent layers' part of the backward pass, top down: the gradient w.r.t. the top layer's output is in gout[N-1][0]
 // (fragments) when this is called -- written by the denoiser's head backward, or by the classifier's (td_cls_backward).
+static TdSideStream *td_side_for(const TdRnnGeom &g, int nbb, td_layer_done_fn layer_done) {
+    // where a sweep leaves most of the chip idle, and not with a per-layer callback (the data-parallel trainer starts a
+    // layer's all-reduce from it, behind an event on the caller's stream)
+    if (layer_done || td_side_gemm_mode() == 0 || nbb * g.dirs * g.nu > TD_SIDE_GEMM_MAX_CUS) return nullptr;
+    return td_side_stream();
+}
+
+// `forked`: the caller has already put work on the side stream (the head's parameter gradients): it is joined here too
 static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, const void *packT, int batch, int L, char *ws,
-                              float *const *grad_layer, td_layer_done_fn layer_done, void *user, hipStream_t stream) {
+                              float *const *grad_layer, td_layer_done_fn layer_done, void *user, hipStream_t stream,
+                              TdSideStream *forked = nullptr) {
     const int N = cfg->layers, D = g.dirs, H = cfg->hidden, G = cfg->gru ? 3 : 4, DH = D * H;
     const TdTrainLayout t = td_train_layout(cfg, g, batch, L);
     const TdPackTGeom tg = td_packT_geom(cfg, g);
     int rc = TD_OK;
     float *dwpart = t.cols >= 4 * 512 ? (float *)(ws + t.dwpart) : nullptr;
-    // The weight-gradient GEMMs beside the sweeps below them (td_side_stream): where a sweep leaves most of the chip idle, and
-    // not with a per-layer callback (the data-parallel trainer starts a layer's all-reduce from it, behind an event on `stream`).
-    TdSideStream *side = nullptr;
-    if (!layer_done && td_side_gemm_mode() != 0 && t.nbb * D * g.nu <= TD_SIDE_GEMM_MAX_CUS) side = td_side_stream();
+    // The weight-gradient GEMMs beside the sweeps below them (td_side_stream)
+    TdSideStream *side = forked ? forked : td_side_for(g, t.nbb, layer_done);
     hipStream_t gstream = side ? side->stream : stream;
     // ---- layers, top down ------------------------------------------------------------------------
     const int KT = D * g.kh;
@@ -1638,6 +1645,7 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
     const TdPackTGeom tg = td_packT_geom(cfg, g);
     char *ws = (char *)workspace;
     const int DH = D * H;
+    TdSideStream *side = nullptr;
 
     // ---- head --------------------------------------------------------------------------------
     TD_HIP(hipMemsetAsync(grad_film, 0, (size_t)batch * 2 * DH * sizeof(float), stream));
@@ -1674,8 +1682,17 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
             rc = cm == 16 ? launch(td_head_bwd_dh_kernel<16, true>, 0) : launch(td_head_bwd_dh_kernel<32, true>, 0);
         }
         if (rc != TD_OK) return rc;
+        // d h is on its way to the top layer's sweep; the head's parameter gradients need nothing further from this stream and
+        // nothing below needs them: beside the sweeps, like the weight-gradient GEMMs (joined in td_layers_backward)
+        side = td_side_for(g, t.nbb, layer_done);
+        hipStream_t pstream = stream;
+        if (side) {
+            TD_HIP(hipEventRecord(side->fork[16], stream));
+            TD_HIP(hipStreamWaitEvent(side->stream, side->fork[16], 0));
+            pstream = side->stream;
+        }
         const int rows = batch * cfg->c_out;
-        hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, stream, grad_y, p.g1, rows, L);
+        hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, pstream, grad_y, p.g1, rows, L);
         TD_LAUNCH_CHECK();
         // about 2048 waves per launch, chunks of at least 16 steps
         p.lch = 2048 / (t.nbb * D * g.kh);
@@ -1684,11 +1701,11 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
         p.llen = td_cdiv(L, p.lch);
         p.lch = td_cdiv(L, p.llen);
         hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16) * p.lch), dim3(256), 0,
-                           stream, p);
+                           pstream, p);
         TD_LAUNCH_CHECK();
     }
     if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
-    return td_layers_backward(cfg, g, packT, batch, L, ws, grad_layer, layer_done, user, stream);
+    return td_layers_backward(cfg, g, packT, batch, L, ws, grad_layer, layer_done, user, stream, side);
 }
 
 
