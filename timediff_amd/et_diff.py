@@ -472,7 +472,8 @@ class ETDiff(nn.Module):
     def _train_step_graphed(self, batches):
         """-> the step's loss, or None while this signature (the micro-batch shapes) is still in its launch-by-launch
         warm-up."""
-        key = tuple((tuple(b.shape), b.dtype) for b in batches)
+        # (Adam's betas and eps are kernel arguments of the captured step: a checkpoint that changes them gets a new graph)
+        key = tuple((tuple(b.shape), b.dtype) for b in batches) + (tuple(self.betas), self.eps)
         ent = self._graphs.get(key)
         if ent is None:
             ent = self._graphs[key] = {"seen": 0}
