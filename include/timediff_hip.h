@@ -147,6 +147,17 @@ TD_API int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, const
                        const float *grad_y, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer_host,
                        float *const *grad_misc_host, float *grad_film, td_layer_done_fn layer_done, void *user, void *stream);
 
+/* td_rnn_backward_cb followed by td_rnn_time_film_backward(cfg, misc, t, batch, grad_film, grad_misc, film_workspace) in ONE
+ * call: the whole backward pass of RNN.forward (blocks.py:333-341 under accelerator.backward, et_diff.py:237) for one film row
+ * per batch element.  grad_misc_host holds all ten entries (the six time-embedding / FiLM-linear parameters are accumulated
+ * as td_rnn_time_film_backward does); grad_film is scratch of the caller's ((batch, 2*D*H), complete when the call's work
+ * is).  What the single call buys: the time-embedding backward runs beside the BPTT sweeps (td_set_side_gemm) instead of
+ * behind them.  film_workspace: td_rnn_time_film_backward_workspace_bytes(cfg, batch) bytes. */
+TD_API int td_rnn_backward_all(const td_rnn_config *cfg, const void *packT, const float *const *misc_host, const float *film,
+                        const int64_t *t, const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
+                        void *film_workspace, float *const *grad_layer_host, float *const *grad_misc_host, float *grad_film,
+                        td_layer_done_fn layer_done, void *user, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Mixed diffusion: models/ETDiff/mixed_diffusion.py MixedDiffusion (:68-454); n_cat = 0 gives
  * models/ETDiff/gaussian_diffusion.py GaussianDiffusion.

@@ -78,6 +78,8 @@ _SIGS = {
                                   C.POINTER(_P), _P, _P]),
     "td_rnn_backward_cb": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _I, _I, _P, C.POINTER(_P),
                                      C.POINTER(_P), _P, LAYER_DONE_FN, _P, _P]),
+    "td_rnn_backward_all": (C.c_int, [C.POINTER(RnnConfig), _P, C.POINTER(_P), _P, _P, _P, _I, _I, _P, _P, C.POINTER(_P),
+                                      C.POINTER(_P), _P, LAYER_DONE_FN, _P, _P]),
     "td_q_sample_mixed": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, Rng, _P, _P, _P, _P, _P]),
     "td_mixed_loss_workspace_bytes": (C.c_size_t, [C.POINTER(DiffusionConfig), _I]),
     "td_mixed_loss": (C.c_int, [C.POINTER(DiffusionConfig), _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),

@@ -43,11 +43,10 @@ class _DenoiserFn(torch.autograd.Function):
             # the trainer's flat gradient buffer: the kernels accumulate straight into the .grad views (no
             # AccumulateGrad pass), and the trainer may start a layer's all-reduce while the layers below are
             # still being differentiated (et_diff.py: ETDiff._layer_reduce)
-            _, _, g_film = k.backward(grad_y.contiguous(), film, sink=sink["tensors"], on_layer_done=sink.get("on_layer_done"))
-            k.time_film_backward(time, g_film, sink=sink["tensors"])
+            # (one call for the recurrent stack, the head AND the time-embedding MLP: the latter runs beside the BPTT sweeps)
+            k.backward(grad_y.contiguous(), film, sink=sink["tensors"], on_layer_done=sink.get("on_layer_done"), time=time)
             return (None, None, None) + (None,) * (len(k._lkeys) + len(_lib.MISC_KEYS))
-        g_layer, g_misc, g_film = k.backward(grad_y.contiguous(), film)
-        g_misc.update(k.time_film_backward(time, g_film))
+        g_layer, g_misc, _ = k.backward(grad_y.contiguous(), film, time=time)
         return (None, None, None, *g_layer, *[g_misc[key] for key in _lib.MISC_KEYS])
 
 

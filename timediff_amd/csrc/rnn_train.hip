@@ -1630,10 +1630,35 @@ extern "C" int td_rnn_backward(const td_rnn_config *cfg, const void *packT, cons
                               nullptr, nullptr, stream_);
 }
 
+extern "C" int td_rnn_time_film_backward(const td_rnn_config *cfg, const float *const *misc, const int64_t *t, int32_t n_t,
+                                         const float *grad_film, float *const *grad_misc, void *workspace, void *stream_);   // rnn.hip
+
+static int td_backward_impl(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                            const float *grad_y, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer,
+                            float *const *grad_misc, float *grad_film, const int64_t *t_steps, void *film_ws,
+                            td_layer_done_fn layer_done, void *user, void *stream_);
+
 extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
                                   const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
                                   float *const *grad_layer, float *const *grad_misc, float *grad_film,
                                   td_layer_done_fn layer_done, void *user, void *stream_) {
+    return td_backward_impl(cfg, packT, misc, film, grad_y, batch, seq_len, workspace, grad_layer, grad_misc, grad_film, nullptr,
+                            nullptr, layer_done, user, stream_);
+}
+
+extern "C" int td_rnn_backward_all(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                                   const int64_t *t, const float *grad_y, int32_t batch, int32_t seq_len, void *workspace,
+                                   void *film_workspace, float *const *grad_layer, float *const *grad_misc, float *grad_film,
+                                   td_layer_done_fn layer_done, void *user, void *stream_) {
+    TD_REQUIRE(t && film_workspace, "NULL argument");
+    return td_backward_impl(cfg, packT, misc, film, grad_y, batch, seq_len, workspace, grad_layer, grad_misc, grad_film, t,
+                            film_workspace, layer_done, user, stream_);
+}
+
+static int td_backward_impl(const td_rnn_config *cfg, const void *packT, const float *const *misc, const float *film,
+                            const float *grad_y, int32_t batch, int32_t seq_len, void *workspace, float *const *grad_layer,
+                            float *const *grad_misc, float *grad_film, const int64_t *t_steps, void *film_ws,
+                            td_layer_done_fn layer_done, void *user, void *stream_) {
     TD_REQUIRE(cfg && packT && misc && film && grad_y && workspace && grad_layer && grad_misc && grad_film, "NULL argument");
     TD_REQUIRE(batch > 0 && seq_len > 0, "batch and seq_len must be positive");
     TdRnnGeom g;
@@ -1703,6 +1728,11 @@ extern "C" int td_rnn_backward_cb(const td_rnn_config *cfg, const void *packT, c
         hipLaunchKernelGGL((td_head_bwd_param_kernel<16>), dim3(t.nbb, td_cdiv(D * g.kh, 4), td_cdiv(cfg->c_out, 16) * p.lch), dim3(256), 0,
                            pstream, p);
         TD_LAUNCH_CHECK();
+        // the time-embedding MLP's backward (d film is complete now): with the head's parameter gradients, beside the sweeps
+        if (t_steps) {
+            rc = td_rnn_time_film_backward(cfg, misc, t_steps, batch, grad_film, grad_misc, film_ws, (void *)pstream);
+            if (rc != TD_OK) return rc;
+        }
     }
     if (layer_done) layer_done(N, user);   // LayerNorm / fc gradients are enqueued
     return td_layers_backward(cfg, g, packT, batch, L, ws, grad_layer, layer_done, user, stream, side);

@@ -209,6 +209,9 @@ class ETDiff(nn.Module):
             self._layer_slices = layer_slices(names, [p.numel() for p in self.params], self._n_layers)
         self.opt_step = 0
         self.step = 0
+        # the batches the trainer hands to the diffusion module are its own device copies: the reference's in-place
+        # normalisation of the caller's batch (mixed_diffusion.py:189-194) would be four kernels that nobody observes
+        self.model._batch_is_private = True
         # One process, one fused batch, no dropout: the whole optimizer step (q_sample ... Adam/EMA, about sixty small
         # launches) is captured once per (batch, L) signature and replayed as ONE graph launch; what changes from step to
         # step (the noise seed, Adam's bias corrections, what the EMA does) is read by the kernels from a device record
@@ -453,11 +456,13 @@ class ETDiff(nn.Module):
         self.model._seed_dev = self._rec
         try:
             with torch.cuda.graph(graph):
-                total = torch.zeros((), dtype=torch.float32, device=self.device)
+                total = None
                 for i, x in enumerate(xs):
                     self.model._seed_base = i       # micro-batch i draws with seed = record's seed + i
-                    loss = self.model(x) / ga
-                    total += loss.detach()
+                    loss = self.model(x)
+                    if ga > 1:
+                        loss = loss / ga
+                    total = loss.detach() if total is None else total + loss.detach()
                     loss.backward()
                 check(lib().td_grad_norm(ptr(self.flat_grad), n, ptr(self._norm), ptr(self._norm_ws), _stream()))
                 check(lib().td_clip_adam_ema_rec(ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
@@ -505,14 +510,16 @@ class ETDiff(nn.Module):
             loss = self._train_step_graphed(batches)
             if loss is not None:
                 return loss
-        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        total = None
         for i, data in enumerate(batches):
             if self._sink is not None:
                 overlap = self._dp and self._overlap and i == ga - 1
                 self._sink["on_layer_done"] = self._layer_reduce if overlap else None
             data = data.to(self.device, non_blocking=True)
-            loss = self.model(data) / ga
-            total += loss.detach()
+            loss = self.model(data)
+            if ga > 1:
+                loss = loss / ga
+            total = loss.detach() if total is None else total + loss.detach()
             loss.backward()
         self._all_reduce_grads()
         self._optimizer_step(update_ema=True)

@@ -119,7 +119,8 @@ class MixedDiffusion(nn.Module):
         x_in, x0_idx, xt_idx, eps = dk.q_sample(sample, t, noise, uniforms, seed=getattr(self, "_seed_base", 0) if seed_dev is not None else _fresh_seed(),
                                                 tag=0x40000000, seed_dev=seed_dev)
         # the reference normalises the caller's batch in place (normalize_numericals, :189-194)
-        if self.auto_normalize:
+        # (a caller that owns the batch and never looks at it again says so: ETDiff's copies of the loader's batches)
+        if self.auto_normalize and not getattr(self, "_batch_is_private", False):
             ch = self._num_idx_dev      # the channel list as a device tensor (a list index is a host-to-device copy per call)
             sample[:, ch, :] = sample[:, ch, :] * 2 - 1
         model_out = self.model(x_in, t, None)

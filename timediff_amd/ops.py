@@ -155,8 +155,10 @@ class DenoiserKernels:
         self._train_shape = (B, L)
         return y
 
-    def backward(self, grad_y, film, sink=None, on_layer_done=None):
+    def backward(self, grad_y, film, sink=None, on_layer_done=None, time=None):
         """Backward of the last forward_train.  -> (layer grads in layer_keys order, {misc key: grad}, grad_film).
+        time: the (B,) int64 time steps the film rows were computed from: the time-embedding MLP's backward then runs inside
+        the same call (td_rnn_backward_all: beside the BPTT sweeps) and {misc key: grad} covers all ten entries.
         sink: {parameter name: fp32 tensor} to ACCUMULATE the parameter gradients into (the trainer's flat gradient
         buffer) instead of fresh tensors; on_layer_done(l): called while the kernels are being enqueued, right after
         the last one that writes layer l's gradients (l = layers: the LayerNorm / fc gradients), see
@@ -166,13 +168,14 @@ class DenoiserKernels:
         if not self._packT_fresh:
             check(lib().td_rnn_pack_weights_T(C.byref(self.cfg), ptr_table(self._lw), ptr(self._packT), _stream()))
             self._packT_fresh = True
+        first = 0 if time is not None else 6       # misc entries 0 .. 5: the time-embedding MLP and the FiLM linear
         if sink is None:
             g_layer = [torch.zeros_like(w) for w in self._lw]
-            g_misc = {k: torch.zeros_like(self._misc[i]) for i, k in enumerate(_lib.MISC_KEYS) if i >= 6}
+            g_misc = {k: torch.zeros_like(self._misc[i]) for i, k in enumerate(_lib.MISC_KEYS) if i >= first}
         else:
             g_layer = [sink[k] for k in self._lkeys]
-            g_misc = {k: sink[k] for i, k in enumerate(_lib.MISC_KEYS) if i >= 6}
-            for g, w in list(zip(g_layer, self._lw)) + [(g_misc[k], self._misc[i]) for i, k in enumerate(_lib.MISC_KEYS) if i >= 6]:
+            g_misc = {k: sink[k] for i, k in enumerate(_lib.MISC_KEYS) if i >= first}
+            for g, w in list(zip(g_layer, self._lw)) + [(g_misc[k], self._misc[i]) for i, k in enumerate(_lib.MISC_KEYS) if i >= first]:
                 assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == w.shape and g.device == w.device
         tab = (C.c_void_p * _lib.TD_MISC_COUNT)(*[g_misc[k].data_ptr() if k in g_misc else None for k in _lib.MISC_KEYS])
         g_film = torch.empty_like(film)
@@ -185,8 +188,15 @@ class DenoiserKernels:
                 failure.append(e)
 
         cb = _lib.LAYER_DONE_FN(_done) if on_layer_done is not None else _lib.LAYER_DONE_FN()
-        check(lib().td_rnn_backward_cb(C.byref(self.cfg), ptr(self._packT), self._misc_tab, ptr(film), ptr(grad_y), B, L,
-                                       ptr(self._train_ws), ptr_table(g_layer), tab, ptr(g_film), cb, None, _stream()))
+        if time is not None:
+            time = time.to(device=self.device, dtype=torch.int64).contiguous()
+            assert time.numel() == B
+            fws = torch.empty(lib().td_rnn_time_film_backward_workspace_bytes(C.byref(self.cfg), B), dtype=torch.uint8, device=self.device)
+            check(lib().td_rnn_backward_all(C.byref(self.cfg), ptr(self._packT), self._misc_tab, ptr(film), ptr(time), ptr(grad_y), B, L,
+                                            ptr(self._train_ws), ptr(fws), ptr_table(g_layer), tab, ptr(g_film), cb, None, _stream()))
+        else:
+            check(lib().td_rnn_backward_cb(C.byref(self.cfg), ptr(self._packT), self._misc_tab, ptr(film), ptr(grad_y), B, L,
+                                           ptr(self._train_ws), ptr_table(g_layer), tab, ptr(g_film), cb, None, _stream()))
         if failure:
             raise failure[0]
         return g_layer, g_misc, g_film
