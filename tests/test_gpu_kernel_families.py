@@ -133,6 +133,19 @@ def test_resident_family_forced(nu, gru, shape, dev, knob):
     _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
 
 
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_resident_kernels_shortest_sequences(L, dev):
+    """One, two and three steps (no hand-over at all / one / two): the loops' first and last iterations are special."""
+    from timediff_amd import _lib
+    H, Cc, n_num, B = 40, 14, 4, 70
+    sd = random_state(H, Cc, 2, 2, 0, seed=L)
+    den = den_kernels(sd, dev)
+    assert _choice(den, B, L) == _lib.LAYER_KERNEL_CLUSTER
+    x, t, rng = _inputs(B, Cc, L, n_num, seed=L + 3)
+    gy = (rng.standard_normal((B, Cc, L)) / (B * L)).astype(np.float32)
+    _check_forward_and_grads(den, sd, x, t, gy, np.arange(B), dev)
+
+
 @pytest.mark.parametrize("H,Cc,n_num,L,gru", [(92, 23, 7, 24, 0), (36, 9, 7, 100, 0), (36, 9, 7, 100, 1)])
 def test_resident_kernels_at_the_reference_shapes(H, Cc, n_num, L, gru, dev):
     """The reference's default widths and lengths (etdiff_train.py:24-29, :239: MIMIC-III H = 92, L = 24; HiRID H = 36,
