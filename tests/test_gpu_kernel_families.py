@@ -263,6 +263,57 @@ def test_large_batch_chain_graph_equals_stepwise(dev, fusion):
     assert np.abs(mo[_lib.HEAD_FUSION_ON] - mo[_lib.HEAD_FUSION_OFF]).max() < 1e-3
 
 
+# (H, L, B, num, cat, K): shapes whose reverse update also packs the next step's layer-0 fragments (L % 4 == 0, K <= 8)
+REVERSE_PACKS = [
+    (92, 24, 70, [0, 2, 4, 6, 8, 10, 12], [1, 3, 5, 7, 9, 11, 13, 14], [2] * 8),   # MIMIC-III: two k-tiles of input, ragged batch
+    (36, 100, 33, [0, 1, 2, 3, 4, 5, 6], [7], [2]),                                 # HiRID: L not a multiple of the 32-position tile
+    (64, 36, 256, [1, 2], [0, 3, 4], [3, 2, 5]),                                    # mixed class counts (the 8-class kernel), L = 32 + 4
+    (48, 8, 5, [0, 1, 2], [], []),                                                  # continuous channels only
+    (48, 8, 40, [], [0, 1], [2, 4]),                                                # discrete variables only
+    # enough 32 x 32 tiles to fill the CUs: one thread updates all channels of its positions (the cases above: four waves share them)
+    (92, 8, 8192 + 40, [0, 2, 4, 6, 8, 10, 12], [1, 3, 5, 7, 9, 11, 13, 14], [2] * 8),
+    (36, 100, 2048 + 5, [0, 1, 2, 3, 4, 5, 6], [7], [2]),
+    (64, 36, 4096 + 33, [1, 2], [0, 3, 4], [3, 2, 5]),
+]
+
+
+@pytest.mark.parametrize("H,L,B,num,cat,K", REVERSE_PACKS)
+def test_chain_reverse_update_packs_next_input(H, L, B, num, cat, K, dev):
+    """From the second step on the chain's layer-0 fragments are written by the reverse update's kernel (diffusion.hip,
+    FRAGS form) instead of a packing kernel of their own: the chain equals the tensor-level composition
+    (build_input -> forward -> reverse_step_, each step packing its own input) bit for bit, graph and eager, with
+    Philox draws and with external ones."""
+    from timediff_amd.ops import DiffusionKernels, SamplerKernels
+    T = 5
+    C_io, Cd = len(num) + sum(K), len(num) + len(cat)
+    sd = random_state(H, C_io, 2, 2, 0, seed=H + L)
+    den = den_kernels(sd, dev)
+    tables = {k: torch.from_numpy(v) for k, v in orc.schedule(T, "cosine").items()}
+    diff = DiffusionKernels(num, cat, K, L, T, tables, Cd, dev)
+    sampler = SamplerKernels(den, diff)
+    film = den.time_film(torch.arange(T, device=dev))
+    g = torch.Generator(device="cpu").manual_seed(B)
+    noise = torch.randn(T + 1, B, max(len(num), 1), L, generator=g)[:, :, :len(num)].contiguous().to(dev)
+    uni = torch.rand(T + 1, B, max(sum(K), 1), L, generator=g)[:, :, :sum(K)].contiguous().to(dev)
+
+    def composed(ext):
+        nz = (lambda j: noise[j] if ext and len(num) else None)
+        un = (lambda j: uni[j] if ext and len(cat) else None)
+        z, idx = diff.prior(B, nz(0), un(0), seed=5, patient0=1000)
+        for j, t in enumerate(reversed(range(T))):
+            mo = den.forward(diff.build_input(z, idx), film=film[t:t + 1])
+            diff.reverse_step_(mo, z, idx, t, nz(j + 1), un(j + 1), seed=5, patient0=1000)
+        return diff.decode(z, idx)
+
+    for ext in (False, True):
+        kw = dict(noise=noise if len(num) else None, uniforms=uni if len(cat) else None) if ext else dict(seed=5, patient0=1000)
+        a = sampler.sample(B, **kw)
+        b = sampler.sample(B, use_graph=False, **kw)
+        assert torch.equal(a, b)
+        assert torch.equal(a, composed(ext))
+        assert torch.isfinite(a).all()
+
+
 # (H, gru, dirs, C, n_num, B): above each switch to the batch-block family
 FUSED_HEAD = [
     (256, 1, 2, 14, 4, 8192 + 40),      # GRU

@@ -11,6 +11,7 @@
 // Gumbel transform keeps libm's logf (its inner logarithm's RELATIVE error becomes an absolute error of the noise).
 #include "common.h"
 #include "rng.h"
+#include "rnn_layout.h"
 
 #define TD_KMAX 8          // classes per discrete variable on the vectorised path (logits of 4 positions in registers)
 #define TD_KMAX_WIDE 32    // any class count the denoiser width allows (c_out <= 32): scalar path
@@ -265,7 +266,24 @@ struct TdRevParams {
     td_rng rng;
     // TERMS kernels only (parity): the posterior terms of the step; nothing is sampled or updated
     float *x0_out, *mean_out, *log_theta_out;
+    // FRAGS kernels only (the sampler's chain): the NEXT step's layer-0 input fragments, nbb batch blocks, kx0 k-tiles
+    char *frags;
+    int nbb, kx0;
 };
+
+// FRAGS forms (the template argument is P, the number of threads that share one item): one workgroup owns 32 sequences x
+// TL = 32 / P positions, keeps the updated state of its tile in LDS (4 bytes per continuous channel, ONE byte per discrete
+// variable: the one-hot log values are rebuilt from the class id) and writes the tile's layer-0 fragments as whole 1 KiB
+// runs, bit for bit what td_state_to_frags_kernel makes of the stored state.  P = 1: a thread updates every channel of its
+// four positions (34-45 KiB of LDS at the reference's datasets: three workgroups per CU).  P = 4, for grids that leave
+// most CUs idle (batch 256): wave p of the workgroup takes every fourth block of four continuous channels and every fourth
+// discrete variable of the SAME 32 sequences x 8 positions, which cuts the chain of dependent loads, Philox calls and
+// logarithms a thread walks through by the same factor (the draws are keyed by (sequence, position, channel block), so who
+// makes them changes nothing).
+static inline size_t td_rf_shm(const td_diffusion_config *c, int kx0, int P) {
+    const int TL = 32 / P;
+    return (size_t)c->n_num * 32 * (TL + 1) * sizeof(float) + (size_t)c->n_cat * 32 * (TL + 4) + (size_t)16 * kx0 * sizeof(int);
+}
 
 // three waves per SIMD (138 registers, no spills).  Measured A/B in one process at B = 16 384, L = 272 (0.164-0.172 ms per
 // launch = 2.5-2.7 TB/s): 3 vs 4 waves per SIMD (the latter spills 60 B per lane) and a capped vs one-item-per-thread grid
@@ -274,9 +292,18 @@ struct TdRevParams {
 #ifndef TD_REV_WAVES
 #define TD_REV_WAVES 3
 #endif
-template <int VEC, int KM, bool TERMS>
+#ifndef TD_REV_SPLIT_BELOW
+#define TD_REV_SPLIT_BELOW 256    // tiles of 32 sequences x 32 positions
+#endif
+template <int VEC, int KM, bool TERMS, int FRAGS>
 __global__ __launch_bounds__(256, TD_REV_WAVES) void td_reverse_step_kernel(TdRevParams p) {
+    static_assert(FRAGS == 0 || ((FRAGS == 1 || FRAGS == 4) && VEC == 4 && !TERMS), "the fragment-writing forms are vectorised sampling kernels");
+    constexpr int P = FRAGS ? FRAGS : 1, TL = 32 / P, RS = TL + 1, IRS = TL + 4;
     const td_diffusion_config &c = p.c;
+    extern __shared__ float rf_tile[];   // FRAGS: z tile [n_num][32][RS], class ids [n_cat][32][IRS], channel codes [16 kx0]
+    float *ztile = rf_tile;
+    uint8_t *itile = (uint8_t *)(rf_tile + (size_t)c.n_num * 32 * RS);
+    int *chan = (int *)(itile + (size_t)c.n_cat * 32 * IRS);
     // per variable: {log K, log q(x_t | x_{t-1}) for the current class, for another class, log((1 - abar_{t-1}) / K)}
     __shared__ float s_var[TD_MAX_CAT][4];
     const int L = c.seq_len, C_io = c.n_num + p.sumk, T = c.timesteps, LQ = L / VEC;
@@ -301,11 +328,11 @@ __global__ __launch_bounds__(256, TD_REV_WAVES) void td_reverse_step_kernel(TdRe
         s_var[threadIdx.x][3] = l1mca - logK;
     }
     __syncthreads();
-    const size_t total = (size_t)p.B * LQ;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / LQ), l0 = (int)(i % LQ) * VEC;
+    // one (sequence, VEC positions) item, or thread `part`'s share of it; trow / irow = its slot in the LDS tiles (FRAGS)
+    auto item = [&](const int b, const int l0, const int trow, const int irow, const int part) {
         TdDraw<VEC> draw(noise, uniforms, p.rng, b, l0, c.n_num, p.sumk, L, (uint32_t)t);
         for (int ch = 0; ch < c.n_num; ++ch) {
+            if (P > 1 && ((ch >> 2) & (P - 1)) != part) continue;
             const size_t zi = ((size_t)b * c.n_num + ch) * L + l0;
             const TdVec<VEC> eps = td_ldf<VEC>(p.mo + ((size_t)b * C_io + ch) * L + l0), zt = td_ldf<VEC>(p.z + zi);
             TdVec<VEC> x0, mean, o;
@@ -327,11 +354,16 @@ __global__ __launch_bounds__(256, TD_REV_WAVES) void td_reverse_step_kernel(TdRe
                     for (int e = 0; e < VEC; ++e) o.v[e] = mean.v[e] + sigma * 0.f;
                 }
                 td_stf<VEC>(p.z + zi, o);
+                if constexpr (FRAGS) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ztile[ch * 32 * RS + trow + e] = o.v[e];
+                }
             }
         }
         int off = 0;
         for (int v = 0; v < c.n_cat; ++v) {
             const int K = c.num_classes[v];
+            if (P > 1 && (v & (P - 1)) != P - 1 - part) { off += K; continue; }   // variables from the last wave down, channel blocks from the first up
             const float w_hit = s_var[v][1], w_miss = s_var[v][2], uni = s_var[v][3];
             const float *zp = p.mo + ((size_t)b * C_io + c.n_num + off) * L + l0;
             float logit[KM][VEC], m[VEC], se[VEC];
@@ -403,8 +435,71 @@ __global__ __launch_bounds__(256, TD_REV_WAVES) void td_reverse_step_kernel(TdRe
                         }
                     }
                 td_stb<VEC>(p.idx + ((size_t)b * c.n_cat + v) * L + l0, best);
+                if constexpr (FRAGS) td_stb<VEC>(itile + v * 32 * IRS + irow, best);
             }
             off += K;
+        }
+    };
+    if constexpr (!FRAGS) {
+        const size_t total = (size_t)p.B * LQ;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            item((int)(i / LQ), (int)(i % LQ) * VEC, 0, 0, 0);
+    } else {
+        const int tid = threadIdx.x, bblk = blockIdx.y, lt0 = blockIdx.x * TL;
+        const int CP = 16 * p.kx0;
+        // channel of the denoiser input -> where its value comes from: a z row, (variable, class), or padding
+        for (int ch = tid; ch < CP; ch += 256) {
+            int code = -1;
+            if (ch < c.n_num) code = ch;
+            else if (ch < C_io) {
+                int v = 0, o = c.n_num;
+                while (ch >= o + c.num_classes[v]) { o += c.num_classes[v]; ++v; }
+                code = 0x10000 | (v << 8) | (ch - o);
+            }
+            chan[ch] = code;
+        }
+        {
+            constexpr int Q = TL / 4;                           // quads of positions per sequence in the tile
+            const int part = tid / (32 * Q), r = tid % (32 * Q), bb = r / Q, ll0 = (r % Q) * 4;
+            const int b = bblk * 32 + bb, l0 = lt0 + ll0;
+            const int trow = bb * RS + ll0, irow = bb * IRS + ll0;
+            if (b < p.B && l0 < L) item(b, l0, trow, irow, part);
+            else {   // rows past the batch pack as zeros (positions past L are never written)
+                for (int ch = 0; ch < c.n_num; ++ch)
+                    if (((ch >> 2) & (P - 1)) == part) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ztile[ch * 32 * RS + trow + e] = 0.f;
+                    }
+                for (int v = 0; v < c.n_cat; ++v)
+                    if ((v & (P - 1)) == P - 1 - part) *(uint32_t *)(itile + v * 32 * IRS + irow) = 0u;
+            }
+        }
+        __syncthreads();
+        const int wave = tid >> 6, lane = tid & 63, m = lane & 31, hf = lane >> 5;
+        const bool row_ok = bblk * 32 + m < p.B;
+        for (int ll = wave; ll < TL; ll += 4) {
+            const int l = lt0 + ll;
+            if (l >= L) break;
+            for (int kx = 0; kx < p.kx0; ++kx) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int code = chan[16 * kx + 8 * hf + j];
+                    float v = 0.f;
+                    if (code >= 0x10000) {
+                        const int cur = itile[((code >> 8) & 255) * 32 * IRS + m * IRS + ll];
+                        v = (!row_ok || (code & 255) == cur) ? 0.f : TD_LOG_1E30;   // mixed_diffusion.py:44-51
+                    } else if (code >= 0) {
+                        v = ztile[(code * 32 + m) * RS + ll];
+                    }
+                    const __bf16 h = (__bf16)v;
+                    hi[j] = h;
+                    lo[j] = (__bf16)(v - (float)h);
+                }
+                char *o = p.frags + (((size_t)l * p.nbb + bblk) * (2 * p.kx0) + 2 * kx) * TD_FRAG_BYTES + lane * 16;
+                *(bf16x8 *)o = hi;
+                *(bf16x8 *)(o + TD_FRAG_BYTES) = lo;
+            }
         }
     }
 }
@@ -418,22 +513,47 @@ static int td_launch_reverse(const TdRevParams &p, hipStream_t stream) {
     const size_t BL = (size_t)p.B * cfg->seq_len;
     // binary variables (every dataset of the reference, etdiff_train.py:24-29) get their own instantiation: the class
     // loops are unrolled to the bound, and 8 classes x 4 positions of logits cost 100 registers more than 2 x 4
+    if constexpr (!TERMS) {
+        if (p.frags) {   // the caller asked td_reverse_fusable() first
+            // fewer 32 x 32 tiles than CUs: four waves share each item (see above)
+            const bool split = (size_t)td_cdiv(cfg->seq_len, 32) * p.nbb < TD_REV_SPLIT_BELOW;
+            const bool k2 = td_max_k(cfg) <= 2;
+            const int P = split ? 4 : 1;
+            const size_t shm = td_rf_shm(cfg, p.kx0, P);
+            const dim3 grid(td_cdiv(cfg->seq_len, 32 / P), p.nbb);
+            const void *fn = split ? (k2 ? (const void *)td_reverse_step_kernel<4, 2, false, 4> : (const void *)td_reverse_step_kernel<4, TD_KMAX, false, 4>)
+                                   : (k2 ? (const void *)td_reverse_step_kernel<4, 2, false, 1> : (const void *)td_reverse_step_kernel<4, TD_KMAX, false, 1>);
+            if (shm > 65536) TD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            void *args[] = {(void *)&p};
+            TD_HIP(hipLaunchKernel(fn, grid, dim3(256), args, shm, stream));
+            return TD_OK;
+        }
+    }
     if (td_max_k(cfg) > TD_KMAX)
-        hipLaunchKernelGGL((td_reverse_step_kernel<1, TD_KMAX_WIDE, TERMS>), dim3(td_grid(BL)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((td_reverse_step_kernel<1, TD_KMAX_WIDE, TERMS, 0>), dim3(td_grid(BL)), dim3(256), 0, stream, p);
     else if (vec && td_max_k(cfg) <= 2)
-        hipLaunchKernelGGL((td_reverse_step_kernel<4, 2, TERMS>), dim3(td_grid(BL / 4)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((td_reverse_step_kernel<4, 2, TERMS, 0>), dim3(td_grid(BL / 4)), dim3(256), 0, stream, p);
     else if (vec)
-        hipLaunchKernelGGL((td_reverse_step_kernel<4, TD_KMAX, TERMS>), dim3(td_grid(BL / 4)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((td_reverse_step_kernel<4, TD_KMAX, TERMS, 0>), dim3(td_grid(BL / 4)), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((td_reverse_step_kernel<1, TD_KMAX, TERMS>), dim3(td_grid(BL)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((td_reverse_step_kernel<1, TD_KMAX, TERMS, 0>), dim3(td_grid(BL)), dim3(256), 0, stream, p);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
 
+// Whether the chain's reverse update can also pack the next step's layer-0 fragments (the vectorised kernel's conditions;
+// the tile must fit one CU's LDS).
+bool td_reverse_fusable(const td_diffusion_config *cfg, const float *mo, const float *z, const uint8_t *idx, const float *noise,
+                        const float *uniforms, size_t noise_stride, size_t uni_stride, int kx0) {
+    return cfg->seq_len % 4 == 0 && td_al16(mo) && td_al16(z) && ((uintptr_t)idx & 3) == 0 && td_al16(noise) && td_al16(uniforms) &&
+           noise_stride % 4 == 0 && uni_stride % 4 == 0 && td_max_k(cfg) <= TD_KMAX && td_rf_shm(cfg, kx0, 1) <= 160 * 1024;
+}
+
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
                            const int32_t *t_dev, int32_t *t_next, const float *noise, const float *uniforms, size_t noise_stride,
-                           size_t uni_stride, td_rng rng, hipStream_t stream) {
+                           size_t uni_stride, td_rng rng, hipStream_t stream, char *frags, int kx0) {
     TdRevParams p;
+    p.frags = frags; p.kx0 = kx0; p.nbb = td_cdiv(batch, 32);
     p.c = *cfg; p.B = batch; p.sumk = td_sum_k(cfg); p.t_host = t_host; p.mo = mo; p.z = z; p.idx = idx; p.t_dev = t_dev;
     p.t_next = t_next;
     p.noise = noise; p.uniforms = uniforms; p.noise_stride = noise_stride; p.uni_stride = uni_stride; p.rng = rng;
@@ -449,7 +569,7 @@ extern "C" int td_reverse_step_mixed(const td_diffusion_config *cfg, int32_t bat
     TD_REQUIRE(model_out && (z || cfg->n_num == 0) && (idx || cfg->n_cat == 0), "NULL argument");
     TD_REQUIRE(t_dev || (t_host >= 0 && t_host < cfg->timesteps), "t = %d outside [0, %d)", t_host, cfg->timesteps);
     return td_launch_reverse_step(cfg, batch, model_out, z, idx, t_host, t_dev, nullptr, noise, uniforms, 0, 0, rng,
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream, nullptr, 0);
 }
 
 extern "C" int td_reverse_step_terms(const td_diffusion_config *cfg, int32_t batch, const float *model_out, const float *z,
@@ -464,6 +584,7 @@ extern "C" int td_reverse_step_terms(const td_diffusion_config *cfg, int32_t bat
     p.t_dev = nullptr; p.t_next = nullptr; p.noise = nullptr; p.uniforms = nullptr; p.noise_stride = 0; p.uni_stride = 0;
     p.rng.seed = 0; p.rng.patient0 = 0; p.rng.tag = 0; p.rng.seed_dev = nullptr;
     p.x0_out = x0; p.mean_out = mean; p.log_theta_out = log_theta;
+    p.frags = nullptr; p.nbb = 0; p.kx0 = 0;
     return td_launch_reverse<true>(p, (hipStream_t)stream);
 }
 

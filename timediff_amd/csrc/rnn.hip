@@ -1039,8 +1039,31 @@ static bool td_head_fusable(const td_rnn_config *cfg, const TdRnnGeom &g, int ba
     return !td_use_cluster(g, nbb, L) && !td_use_wide(g, nbb);
 }
 
-// The whole denoiser: layer-0 fragments (from x, or from the sampler's diffusion state z / idx), the recurrent layers, the
-// head -> y (B, C_out, L).
+// Sampler: the layer-0 fragments of the diffusion state (z, idx) into the denoiser workspace (they sit at its start);
+// *kx0 = the k-tiles of the layer-0 input.  The chain calls it once, after the prior: from then on the reverse update's
+// kernel leaves the next step's fragments there itself (diffusion.hip, FRAGS form).
+int td_rnn_state_frags(const td_rnn_config *cfg, const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, int batch,
+                       int L, void *workspace, hipStream_t stream, int *kx0) {
+    TdRnnGeom g;
+    int rc = td_rnn_geom(cfg, &g);
+    if (rc != TD_OK) return rc;
+    int sumk = 0;
+    for (int v = 0; v < dcfg->n_cat; ++v) sumk += dcfg->num_classes[v];
+    TD_REQUIRE(dcfg->n_num + sumk == cfg->c_in && dcfg->seq_len == L, "diffusion state does not match the denoiser input");
+    if (kx0) *kx0 = g.kx0;
+    if (!z && !idx) return TD_OK;   // geometry only
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    const size_t sf_shm = (size_t)16 * g.kx0 * 32 * (TD_SF_LT + 1) * sizeof(float);
+    if (sf_shm > 65536)
+        TD_HIP(hipFuncSetAttribute((const void *)td_state_to_frags_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_shm));
+    hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), sf_shm, stream, *dcfg, sumk, z, idx,
+                       (char *)workspace, batch, nbb, g.kx0);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+// The whole denoiser: layer-0 fragments (from x, from the sampler's diffusion state z / idx, or already in the workspace
+// when x, z and idx are all NULL), the recurrent layers, the head -> y (B, C_out, L).
 int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,
                    const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, const float *film, int film_rows,
                    const int32_t *film_row, int batch, int L, float *y, void *workspace, hipStream_t stream, bool chain) {
@@ -1051,16 +1074,9 @@ int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *co
     td_ws_layout(g, batch, L, &x0_bytes, &act_bytes);
     char *x0 = (char *)workspace, *actA = x0 + x0_bytes, *actB = actA + act_bytes;
     const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
-    if (!x) {   // sampler path: the layer-0 fragments come straight from the diffusion state
-        int sumk = 0;
-        for (int v = 0; v < dcfg->n_cat; ++v) sumk += dcfg->num_classes[v];
-        TD_REQUIRE(dcfg->n_num + sumk == cfg->c_in && dcfg->seq_len == L, "diffusion state does not match the denoiser input");
-        const size_t sf_shm = (size_t)16 * g.kx0 * 32 * (TD_SF_LT + 1) * sizeof(float);
-        if (sf_shm > 65536)
-            TD_HIP(hipFuncSetAttribute((const void *)td_state_to_frags_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_shm));
-        hipLaunchKernelGGL(td_state_to_frags_kernel, dim3(td_cdiv(L, TD_SF_LT), nbb), dim3(256), sf_shm, stream, *dcfg, sumk, z, idx,
-                           x0, batch, nbb, g.kx0);
-        TD_LAUNCH_CHECK();
+    if (!x && (z || idx)) {   // sampler path: the layer-0 fragments come straight from the diffusion state
+        rc = td_rnn_state_frags(cfg, dcfg, z, idx, batch, L, workspace, stream, nullptr);
+        if (rc != TD_OK) return rc;
     }
     char *acts[16];
     for (int l = 0; l < cfg->layers; ++l) acts[l] = (l & 1) ? actB : actA;

@@ -11,9 +11,13 @@
 int td_rnn_denoise(const td_rnn_config *cfg, const void *packed, const float *const *misc, const float *x,
                    const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, const float *film, int film_rows,
                    const int32_t *film_row, int batch, int L, float *y, void *workspace, hipStream_t stream, bool chain);
+int td_rnn_state_frags(const td_rnn_config *cfg, const td_diffusion_config *dcfg, const float *z, const uint8_t *idx, int batch,
+                       int L, void *workspace, hipStream_t stream, int *kx0);
 int td_launch_reverse_step(const td_diffusion_config *cfg, int batch, const float *mo, float *z, uint8_t *idx, int t_host,
                            const int32_t *t_dev, int32_t *t_next, const float *noise, const float *uniforms, size_t noise_stride,
-                           size_t uni_stride, td_rng rng, hipStream_t stream);
+                           size_t uni_stride, td_rng rng, hipStream_t stream, char *frags, int kx0);
+bool td_reverse_fusable(const td_diffusion_config *cfg, const float *mo, const float *z, const uint8_t *idx, const float *noise,
+                        const float *uniforms, size_t noise_stride, size_t uni_stride, int kx0);
 
 __global__ void td_set_counter_kernel(int32_t *p, int32_t v) { p[0] = v; }
 
@@ -99,15 +103,27 @@ extern "C" int td_sample_chain(const td_rnn_config *rnn, const td_diffusion_conf
     hipLaunchKernelGGL(td_set_counter_kernel, dim3(1), dim3(1), 0, stream, counter, T - 1);
     TD_LAUNCH_CHECK();
 
+    // The denoiser input (mixed_diffusion.py:439) reaches layer 0 as packed fragments at the start of the denoiser
+    // workspace.  Packed once here from the prior; every reverse update then leaves the next step's fragments there
+    // itself (one kernel fewer per step: 5 % of a step at the MIMIC-III shape).  States the vectorised update does not
+    // take (L % 4, more than 8 classes) are packed by a kernel of their own at the head of every step instead.
+    int kx0 = 0;
+    rc = td_rnn_state_frags(rnn, cfg, nullptr, nullptr, batch, L, rnn_ws, stream, &kx0);
+    if (rc != TD_OK) return rc;
+    const bool fused = td_reverse_fusable(cfg, mo, z, idx, noise, uniforms, noise ? nstride : 0, uniforms ? ustride : 0, kx0);
+    if (fused) {
+        rc = td_rnn_state_frags(rnn, cfg, z, idx, batch, L, rnn_ws, stream, nullptr);
+        if (rc != TD_OK) return rc;
+    }
     auto enqueue_step = [&](int j) -> int {
         int r;
         int32_t *t_now = counter + (j & 1), *t_next = counter + ((j + 1) & 1);
-        // denoiser input (mixed_diffusion.py:439) and its layer-0 fragment packing in one pass, the layers, the head
-        // (fused into the top layer's kernel where the batch-block family runs it)
-        r = td_rnn_denoise(rnn, packed, misc, nullptr, cfg, z, idx, film_table, T, t_now, batch, L, mo, rnn_ws, stream, true);
+        // the layers and the head (fused into the top layer's kernel where the batch-block family runs it)
+        r = td_rnn_denoise(rnn, packed, misc, nullptr, cfg, fused ? nullptr : z, fused ? nullptr : idx, film_table, T, t_now, batch, L,
+                           mo, rnn_ws, stream, true);
         if (r != TD_OK) return r;
         return td_launch_reverse_step(cfg, batch, mo, z, idx, 0, t_now, t_next, noise, uniforms, noise ? nstride : 0,
-                                      uniforms ? ustride : 0, rng, stream);
+                                      uniforms ? ustride : 0, rng, stream, fused ? (char *)rnn_ws : nullptr, kx0);
     };
 
     // One graph launch carries several steps: a launch costs the GPU an idle gap of the order of a millisecond
