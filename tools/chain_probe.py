@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One sampler chain at a reference shape (for timelines): python3 tools/chain_probe.py <mimiciii|hirid> <batch> [T]"""
+"""One sampler chain at a reference shape (for timelines): python3 tools/chain_probe.py <mimiciii|hirid|eicu> <batch> [T]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import init_state  # noqa: E402
+from bench import EICU, init_state  # noqa: E402
 from tools.config_bench import SHAPES  # noqa: E402
 
 
@@ -17,7 +17,7 @@ def main():
     from timediff_amd.schedule import make_tables
     name, B = sys.argv[1], int(sys.argv[2])
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-    cols, L, H = SHAPES[name]
+    cols, L, H = dict(SHAPES, eicu=(EICU, 272, 256))[name]
     dev = torch.device("cuda:0")
     C_io, C = len(cols["num"]) + sum(cols["K"]), len(cols["num"]) + len(cols["cat"])
     den = DenoiserKernels({k: v.to(dev) for k, v in init_state(C_io, H, 3, 2, seed=2023).items()})
