@@ -16,8 +16,8 @@
  *     enqueues work and takes its scratch through the `workspace` arguments sized by the matching
  *     *_bytes() query.  Exceptions, each once per process: td_sample_chain instantiates and caches a hipGraph
  *     (released by td_sample_chain_release); td_profile_enable creates HIP events; the first td_rnn_pack_weights
- *     allocates 64 bytes of device-writable host memory (td_check_async_errors); td_rnn_backward creates one stream and
- *     18 events per device at its first small-batch call (td_set_side_gemm).  The library links no vendor
+ *     allocates 64 bytes of device-writable host memory (td_check_async_errors); td_rnn_backward creates two streams and
+ *     19 events per device at its first small-batch call (td_set_side_gemm).  The library links no vendor
  *     math library: every GEMM on the path is a kernel of this tree;
  *   - limits of this build: hidden <= 1024, c_in <= 32, c_out <= 32, at most TD_MAX_CAT discrete variables
  *     of at most TD_MAX_CLASSES classes each (the reference accepts any K_i, mixed_diffusion.py:44-51);
@@ -352,11 +352,12 @@ TD_API int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batch, i
  * film_row given) -- td_rnn_read_hidden then has no activations of the last layer to read. */
 enum { TD_HEAD_FUSION_AUTO = 0, TD_HEAD_FUSION_OFF = 1, TD_HEAD_FUSION_ON = 2 };
 TD_API int td_set_head_fusion(int32_t mode);
-/* td_rnn_backward without a layer_done callback runs a layer's weight-gradient GEMMs (and the head's parameter gradients) on a stream of the library's own, beside
+/* td_rnn_backward without a layer_done callback runs a layer's weight-gradient GEMMs on a stream of the library's own (and
+ * the head's parameter gradients with the time-embedding backward on a second one), beside
  * the BPTT sweeps of the layers below (forked behind an event on the caller's stream after that layer's sweep, joined before
  * the call returns its last enqueue: the caller's stream order is all a caller needs; a graph capture of the caller's
  * stream captures the fork and join), where the sweep leaves most of the chip idle (small batches).  on = 0: everything on
- * the caller's stream (A/B measurements, tests).  The stream and its events are created at the first such call on a device.
+ * the caller's stream (A/B measurements, tests).  The two streams and their events are created at the first such call on a device.
  * No counterpart in the reference. */
 TD_API int td_set_side_gemm(int32_t on);
 

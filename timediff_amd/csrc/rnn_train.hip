@@ -1448,14 +1448,17 @@ __global__ __launch_bounds__(256) void td_bias_reduce_kernel(const __bf16 *A, si
 // A second stream of the library's own for the weight-gradient GEMMs.  At the reference's batch the BPTT sweep of a layer keeps
 // 32 of the 256 CUs busy for 0.8 ms; the GEMMs of the layer above (which read only that layer's d a and the activations the
 // forward pass saved) need nothing from it and nothing needs them before the optimizer step, so they run beside it: forked
-// behind an event after the layer's sweep, joined at the end of the backward pass.  One stream and 18 events per device,
-// created at the first use (the same fork / join is captured as such when the caller's stream is under graph capture).
+// behind an event after the layer's sweep, joined at the end of the backward pass.  A second side stream carries the head's
+// parameter gradients and the time-embedding MLP's backward (td_backward_impl): at the narrow widths the side work is longer
+// than the sweeps (MIMIC-III shape, batch 256: 270 us of GEMMs + 280 us of head / time-MLP kernels against 260 us of sweeps),
+// so the two kinds run beside each other as well.  Two streams and 19 events per device, created at the first use (the same
+// forks / joins are captured as such when the caller's stream is under graph capture).
 #ifndef TD_SIDE_GEMM_MAX_CUS
 #define TD_SIDE_GEMM_MAX_CUS 64     // CUs a sweep occupies (measured at H = 256: 32 CUs +3.7 %, 128 CUs -7 %)
 #endif
 struct TdSideStream {
-    hipStream_t stream;
-    hipEvent_t fork[17], join;      // one per layer + the head
+    hipStream_t stream, stream2;            // weight-gradient GEMMs; head parameter gradients + time-embedding backward
+    hipEvent_t fork[17], join, join2;       // one fork per layer + the head
     bool ready;
 };
 static TdSideStream *td_side_stream(void) {
@@ -1465,9 +1468,11 @@ static TdSideStream *td_side_stream(void) {
     TdSideStream &s = side[dev];
     if (!s.ready) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 0; i < 17; ++i)
             if (hipEventCreateWithFlags(&s.fork[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
         s.ready = true;
     }
     return &s;
@@ -1483,7 +1488,7 @@ static TdSideStream *td_side_for(const TdRnnGeom &g, int nbb, td_layer_done_fn l
     return td_side_stream();
 }
 
-// `forked`: the caller has already put work on the side stream (the head's parameter gradients): it is joined here too
+// `forked`: the caller has already put work on the second side stream (the head's parameter gradients): it is joined here too
 static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, const void *packT, int batch, int L, char *ws,
                               float *const *grad_layer, td_layer_done_fn layer_done, void *user, hipStream_t stream,
                               TdSideStream *forked = nullptr) {
@@ -1619,6 +1624,10 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
     if (side) {
         TD_HIP(hipEventRecord(side->join, side->stream));
         TD_HIP(hipStreamWaitEvent(stream, side->join, 0));
+        if (forked) {
+            TD_HIP(hipEventRecord(side->join2, side->stream2));
+            TD_HIP(hipStreamWaitEvent(stream, side->join2, 0));
+        }
     }
     return TD_OK;
 }
@@ -1713,8 +1722,8 @@ static int td_backward_impl(const td_rnn_config *cfg, const void *packT, const f
         hipStream_t pstream = stream;
         if (side) {
             TD_HIP(hipEventRecord(side->fork[16], stream));
-            TD_HIP(hipStreamWaitEvent(side->stream, side->fork[16], 0));
-            pstream = side->stream;
+            TD_HIP(hipStreamWaitEvent(side->stream2, side->fork[16], 0));
+            pstream = side->stream2;
         }
         const int rows = batch * cfg->c_out;
         hipLaunchKernelGGL(td_rowsum_kernel, dim3(td_cdiv(rows, 4)), dim3(256), 0, pstream, grad_y, p.g1, rows, L);

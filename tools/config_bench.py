@@ -44,7 +44,7 @@ def main():
             out["sampler"][str(B)] = {"reverse_step_ms": step * 1e3, "sequences_per_s_at_T1000": B / (step * 1000)}
         del sampler, diff, den
         torch.cuda.empty_cache()
-        r = train_probe(dev, cols, L, H, N, 1000, 256, 1, 20, 3)
+        r = train_probe(dev, cols, L, H, N, 1000, 256, 1, 200, 10)      # a 1 ms step: enough of them that the capture and the first replays do not weigh
         out["train_batch256"] = {"optimizer_steps_per_s": r["value"], "ms_per_step": r["ms_per_step"]}
         print(json.dumps(out), flush=True)
 

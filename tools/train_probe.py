@@ -18,6 +18,8 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--seq-len", type=int, default=272)
+ap.add_argument("--shape", default="eicu", help="eicu (bench.py), or mimiciii / hirid at their reference widths (tools/config_bench.py); "
+                                               "the latter set --hidden and --seq-len themselves")
 ap.add_argument("--no-side-gemm", action="store_true", help="weight-gradient GEMMs on the caller's stream (td_set_side_gemm(0))")
 ap.add_argument("--loop", action="store_true", help="gradient accumulation as a loop over micro-batches (the reference's form)")
 a = ap.parse_args()
@@ -25,4 +27,8 @@ torch.cuda.set_device(0)
 if a.no_side_gemm:
     from timediff_amd import _lib
     _lib.check(_lib.lib().td_set_side_gemm(0))
-print(json.dumps(train_probe(torch.device("cuda", 0), EICU, a.seq_len, a.hidden, 3, 1000, a.batch, a.ga, a.steps, a.warmup, fuse=not a.loop)))
+cols = EICU
+if a.shape != "eicu":
+    from tools.config_bench import SHAPES
+    cols, a.seq_len, a.hidden = SHAPES[a.shape]
+print(json.dumps(train_probe(torch.device("cuda", 0), cols, a.seq_len, a.hidden, 3, 1000, a.batch, a.ga, a.steps, a.warmup, fuse=not a.loop)))
