@@ -360,6 +360,13 @@ TD_API int td_set_head_fusion(int32_t mode);
  * the caller's stream (A/B measurements, tests).  The two streams and their events are created at the first such call on a device.
  * No counterpart in the reference. */
 TD_API int td_set_side_gemm(int32_t on);
+/* The unit-split family's layers (forward and BPTT sweep) as one launch per time step instead of one persistent launch per
+ * layer.  AUTO: hidden sizes above 256 at batches of at most 128 (batch block, direction) pairs, where the persistent
+ * kernels leave most of the chip idle behind one CU's L2 port (77 -> 12 us per step at H = 512, batch 512); ON: every
+ * width of whole groups of four unit blocks (H padded to a multiple of 128) whenever that family runs; OFF: never.
+ * Bit-identical results either way.  No counterpart in the reference. */
+enum { TD_STEP_LAUNCH_AUTO = 0, TD_STEP_LAUNCH_OFF = 1, TD_STEP_LAUNCH_ON = 2 };
+TD_API int td_set_step_launch(int32_t mode);
 
 /* No counterpart in the reference.  The cluster-persistent kernels (small batches at hidden 193..256; the one-workgroup form
  * at hidden <= 96 has no hand-off between workgroups and cannot raise this) need every workgroup of a launch resident at once.  Where the device cannot give that (shared with another process, CU mask) a bounded poll

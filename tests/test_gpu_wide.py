@@ -125,3 +125,62 @@ def test_wide_denoiser_backward(H, layers, dirs, gru, C, n_num, B, L, dev):
         assert _rel(got.cpu().numpy(), ref[key]) < 3e-2, (key, _rel(got.cpu().numpy(), ref[key]))
     np.testing.assert_allclose(g_film.sum(0).cpu().numpy(), ref["rnn.time_mlp.1.bias"], rtol=3e-2,
                                atol=3e-2 * np.abs(ref["rnn.time_mlp.1.bias"]).max())
+
+
+@pytest.fixture
+def step_launch():
+    from timediff_amd import _lib
+
+    def set_mode(mode):
+        _lib.check(_lib.lib().td_set_step_launch(mode))
+    yield set_mode
+    _lib.check(_lib.lib().td_set_step_launch(_lib.STEP_LAUNCH_AUTO))
+    _lib.check(_lib.lib().td_set_layer_kernel(_lib.LAYER_KERNEL_AUTO))
+
+
+# (H, layers, dirs, gru, C, n_num, B, L)
+STEP_LAUNCH = [
+    (512, 3, 2, 0, 14, 4, 70, 6),       # 16 unit blocks, three batch blocks, the last ragged
+    (320, 2, 2, 1, 9, 7, 33, 5),        # GRU, 10 blocks padded to 12
+    (768, 2, 1, 0, 23, 7, 40, 4),       # unidirectional, two layer-0 input k-steps
+    (1024, 2, 2, 0, 9, 7, 1040, 3),     # two batch blocks per wave (more than 512 tasks), an odd block count: the last twice
+    (256, 2, 2, 0, 14, 4, 40, 6),       # forced below the widths AUTO takes: 8 blocks, bias gradients through the reduction
+    (128, 2, 1, 1, 9, 7, 33, 5),        # ... 4 blocks, GRU
+]
+
+
+@pytest.mark.parametrize("H,layers,dirs,gru,C,n_num,B,L", STEP_LAUNCH)
+def test_step_launch_equals_persistent_kernels(H, layers, dirs, gru, C, n_num, B, L, dev, step_launch):
+    """The unit-split family as one launch per time step (rnn_wide.hip: td_rnn_step_wide_kernel, rnn_train.hip:
+    td_bptt_step_kernel; AUTO takes it above H = 256 at small batches) against the persistent kernels of the same family:
+    the same MFMA order and gate arithmetic, so outputs, saved activations' consequences and every gradient are bit-identical
+    (bias gradients of widths up to 256 aside: the persistent sweep sums d a in fp32 registers, the per-step form reduces
+    the bf16 copy the GEMMs read, as every wide layer does)."""
+    from timediff_amd import _lib
+    sd = random_state(H, C, layers, dirs, gru, seed=H + B)
+    den = den_kernels(sd, dev)
+    x, t, rng = _inputs(B, C, L, n_num, seed=H + 3)
+    gy = (rng.standard_normal((B, C, L)) / (B * L)).astype(np.float32)
+    if H <= 256:
+        _lib.check(_lib.lib().td_set_layer_kernel(_lib.LAYER_KERNEL_UNITS))
+    film = den.time_film(cu(t, dev))
+    out = {}
+    for mode in (_lib.STEP_LAUNCH_OFF, _lib.STEP_LAUNCH_ON):
+        step_launch(mode)
+        y, hidden = den.forward(cu(x, dev), cu(t, dev), want_hidden=True)
+        y_tr = den.forward_train(cu(x, dev), film)
+        g_layer, g_misc, g_film = den.backward(cu(gy, dev), film)
+        out[mode] = dict(y=y, hidden=hidden, y_tr=y_tr, g_film=g_film, **{k: v.clone() for k, v in zip(den._lkeys, g_layer)},
+                         **{"misc." + k: v.clone() for k, v in g_misc.items()})
+    a, b = out[_lib.STEP_LAUNCH_OFF], out[_lib.STEP_LAUNCH_ON]
+    assert torch.isfinite(b["y"]).all()
+    for key in a:
+        if H <= 256 and "bias_" in key:
+            assert _rel(b[key].cpu().numpy(), a[key].cpu().numpy()) < 1e-2, key
+        elif key.startswith("misc."):      # the head's parameter gradients are sums of atomics: equal up to their order
+            assert _rel(b[key].cpu().numpy(), a[key].cpu().numpy()) < 1e-5, key
+        else:
+            assert torch.equal(a[key], b[key]), key
+    step_launch(_lib.STEP_LAUNCH_AUTO)
+    want = _lib.STEP_LAUNCH_ON if H > 256 and -(-B // 32) * dirs <= 128 else _lib.STEP_LAUNCH_OFF
+    np.testing.assert_array_equal(den.forward(cu(x, dev), cu(t, dev)).cpu().numpy(), out[want]["y"].cpu().numpy())

@@ -23,6 +23,7 @@ MISC_KEYS = ["time_emb.1.weight", "time_emb.1.bias", "time_emb.3.weight", "time_
 LAYER_KERNEL_AUTO, LAYER_KERNEL_BATCH, LAYER_KERNEL_UNITS, LAYER_KERNEL_CLUSTER = 0, 1, 2, 3     # td_set_layer_kernel
 PROFILE_LAYER_INFER, PROFILE_LAYER_SAVE, PROFILE_BPTT_SWEEP = 1, 2, 4     # td_profile_enable
 HEAD_FUSION_AUTO, HEAD_FUSION_OFF, HEAD_FUSION_ON = 0, 1, 2             # td_set_head_fusion
+STEP_LAUNCH_AUTO, STEP_LAUNCH_OFF, STEP_LAUNCH_ON = 0, 1, 2             # td_set_step_launch
 
 
 class RnnConfig(C.Structure):
@@ -106,6 +107,7 @@ _SIGS = {
     "td_cls_backward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(_P), _P, _P, _P]),
     "td_set_head_fusion": (C.c_int, [_I]),
     "td_set_side_gemm": (C.c_int, [_I]),
+    "td_set_step_launch": (C.c_int, [_I]),
     "td_check_async_errors": (C.c_int, []),
     "td_profile_enable": (C.c_int, [_I]),
     "td_profile_read": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_float)]),

@@ -40,6 +40,17 @@ extern "C" int td_set_side_gemm(int32_t on) {
     return TD_OK;
 }
 
+static int g_step_launch = TD_STEP_LAUNCH_AUTO;
+int td_step_launch_mode(void) { return g_step_launch; }
+extern "C" int td_set_step_launch(int32_t mode) {
+    if (mode != TD_STEP_LAUNCH_AUTO && mode != TD_STEP_LAUNCH_OFF && mode != TD_STEP_LAUNCH_ON) {
+        td_set_error("td_set_step_launch: unknown mode %d", mode);
+        return TD_ERR_INVALID;
+    }
+    g_step_launch = mode;
+    return TD_OK;
+}
+
 extern "C" int td_set_layer_kernel(int32_t mode) {
     if (mode != TD_LAYER_KERNEL_AUTO && mode != TD_LAYER_KERNEL_BATCH && mode != TD_LAYER_KERNEL_UNITS && mode != TD_LAYER_KERNEL_CLUSTER) {
         td_set_error("td_set_layer_kernel: unknown mode %d", mode);

@@ -17,6 +17,22 @@ struct TdRnnGeom {
 };
 #define TD_CLUSTER_NU 8
 
+// The unit-split family (rnn_wide.hip, and the wide BPTT sweep of rnn_train.hip) as ONE LAUNCH PER TIME STEP: wide layers
+// (more than 8 unit blocks) at batches whose persistent kernels would leave most CUs idle behind one CU's L2 port.
+// td_set_step_launch(ON) takes every width of whole groups of four unit blocks (tests, measurements).
+int td_step_launch_mode(void);   // api.cpp
+#ifndef TD_STEP_LAUNCH_MAX_WG
+#define TD_STEP_LAUNCH_MAX_WG 128    // persistent workgroups (batch blocks x directions) up to which AUTO launches per step
+                                     // (measured at H = 512 / 1024: 2.8x / 4.9x faster at 16 workgroups, 1.2x at 128)
+#endif
+static inline bool td_use_step_launch(int nu, int nbb, int dirs) {
+    if (nu % 4 != 0) return false;               // the kernels' pipeline works chunks of four k-steps
+    const int m = td_step_launch_mode();
+    if (m == TD_STEP_LAUNCH_OFF) return false;
+    if (m == TD_STEP_LAUNCH_ON) return true;
+    return nu > 8 && nbb * dirs <= TD_STEP_LAUNCH_MAX_WG;
+}
+
 static inline int td_rnn_geom(const td_rnn_config *cfg, TdRnnGeom *g) {
     TD_REQUIRE(cfg != nullptr, "td_rnn_config is NULL");
     TD_REQUIRE(cfg->dirs == 1 || cfg->dirs == 2, "dirs must be 1 or 2, got %d", cfg->dirs);

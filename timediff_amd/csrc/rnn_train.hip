@@ -1219,6 +1219,149 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The wide sweep with ONE launch per time step (td_use_step_launch, rnn_geom.h; the forward's counterpart is
+// td_rnn_step_wide_kernel): a wave owns one (unit block, batch block, direction) of one step, so nu * dirs * batch
+// blocks waves spread over the chip instead of 8 waves per (batch block, direction) pulling all of W_hh^T (2 MiB at
+// H = 512) through one CU every step (53 us per step at H = 512).  d a of the step before comes back from the copy that
+// goes to HBM anyway (a kernel boundary lies in between: no fence), the d c / d h carry of a block lives in `carry`
+// ([dir][bblk][u][64 lanes][16] fp32, the forward's state scratch) between launches.  Same order of the MFMAs and the
+// same gate-gradient arithmetic as the WIDE sweep above: bit-identical d a.
+// ---------------------------------------------------------------------------------------------
+#ifndef TD_BPTT_STEP_RING
+#define TD_BPTT_STEP_RING 24    // fragment pairs in flight per wave (48 KiB): the product is bound by L2 latency, not by its 128 MFMAs
+#endif
+__global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, float *carry_buf, size_t carry_dir, int s) {
+    const TdBpttParams &p = q.b;
+    const int lane = threadIdx.x & 63, hf = lane >> 5, m = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int slices = p.nu * p.dirs;
+    const int slice = blockIdx.x % slices, grp = blockIdx.x / slices;
+    const int u = slice % p.nu, d = slice / p.nu;
+    const int bblk = grp * nw + wave;
+    if (bblk >= p.nbb) return;                       // (no barrier in this kernel)
+    const size_t stage_bytes = (size_t)4 * p.kh * TD_FRAG_BYTES;
+    const size_t cols = (size_t)p.L * p.nbb * 32;
+    const int hpad = p.kh * 16;
+    const unsigned slabs = (unsigned)q.slab[0] | (unsigned)q.slab[1] << 4 | (unsigned)q.slab[2] << 8 | (unsigned)q.slab[3] << 12;
+    const int pos = p.L - 1 - s;                     // position in the direction's forward order
+    const int l = d ? p.L - 1 - pos : pos;
+    const int lprev = d ? l + 1 : l - 1;             // the step processed before l in the forward pass
+    const int lnext = d ? l - 1 : l + 1;             // ... and after it: the sweep's previous step
+    const bool has_prev = pos > 0;
+    f32x4 dh[4], carry[4];
+    float *cp = carry_buf + (size_t)d * carry_dir + (((size_t)bblk * p.nu + u) * 64 + lane) * 16;
+    if (s > 0) {
+        // d h_t[this unit block] = W_hh^T x d a_{t+1}: both operands from L2, the loads RING fragment pairs ahead of their MFMA
+        const bf16x8 *wp = (const bf16x8 *)(q.wt + (size_t)d * q.wt_dir + (size_t)u * q.nterm * p.kh * TD_FRAG_BYTES) + lane;
+        const char *dab = p.daf + (size_t)d * p.daf_dir + ((size_t)lnext * p.nbb + bblk) * stage_bytes;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        constexpr int RING = TD_BPTT_STEP_RING;
+        const int total = q.nterm * p.kh;
+        auto bfrag = [&](int idx) {
+            const int term = idx / p.kh, ks = idx - term * p.kh;
+            const int sl = (int)((slabs >> (4 * term)) & 15u);
+            return *((const bf16x8 *)(dab + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
+        };
+        bf16x8 ra[RING], rb[RING];
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int idx = j < total ? j : total - 1;
+            ra[j] = wp[(size_t)idx * 64];
+            rb[j] = bfrag(idx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int i0 = 0; i0 < total; i0 += RING) {
+#pragma unroll
+            for (int j = 0; j < RING; ++j) {
+                if (i0 + j < total) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[j], rb[j], acc, 0, 0, 0);
+                const int nx = i0 + j + RING < total ? i0 + j + RING : total - 1;
+                ra[j] = wp[(size_t)nx * 64];
+                rb[j] = bfrag(nx);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r >> 2][r & 3] = acc[r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) carry[k] = *(const f32x4 *)(cp + 4 * k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dh[k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    for (int sidx = 0; sidx < p.n_src; ++sidx) {
+        const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+        const bf16x8 a = gp[0], b = gp[64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dh[j >> 2][j & 3] += (float)a[j]; dh[2 + (j >> 2)][j & 3] += (float)b[j]; }
+    }
+    const f32x4 *sv = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16);
+    const f32x4 *svp = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float da[4][8];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = 2 * half + kk;
+            const f32x4 s0 = sv[k], s1 = sv[256 + k], s2 = sv[512 + k], s3 = sv[768 + k], s4 = sv[1024 + k];
+            const f32x4 pv = has_prev ? svp[k] : f32x4{0.f, 0.f, 0.f, 0.f};   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * kk + e;
+                const float g = dh[k][e], prev = pv[e];
+                if (!p.gru) {
+                    const float ig = s0[e], fg = s1[e], gg = s2[e], og = s3[e], cv = s4[e];
+                    const float tc = td_tanh(cv);
+                    const float dcv = carry[k][e] + g * og * (1.0f - tc * tc);
+                    da[0][r] = dcv * gg * ig * (1.0f - ig);
+                    da[1][r] = dcv * prev * fg * (1.0f - fg);
+                    da[2][r] = dcv * ig * (1.0f - gg * gg);
+                    da[3][r] = g * tc * og * (1.0f - og);
+                    carry[k][e] = dcv * fg;
+                } else {
+                    const float rg = s0[e], zg = s1[e], ng = s2[e], hn = s3[e];
+                    const float dht = g + carry[k][e];
+                    const float dan = dht * (1.0f - zg) * (1.0f - ng * ng);
+                    da[0][r] = dan * hn * rg * (1.0f - rg);
+                    da[1][r] = dht * (prev - ng) * zg * (1.0f - zg);
+                    da[2][r] = dan;
+                    da[3][r] = dan * rg;
+                    carry[k][e] = dht * zg;
+                }
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (__bf16)da[gi][j];
+            *((bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
+            __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int unit = 32 * u + (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * hf;
+                pl[(size_t)unit * cols] = a[j];
+            }
+        }
+    }
+    if (s + 1 < p.L) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4 *)(cp + 4 * k) = carry[k];
+    }
+}
+
+static int td_launch_bptt_steps(const TdSweepParams &q, float *carry, size_t carry_dir, hipStream_t stream) {
+    const TdBpttParams &p = q.b;
+    int nw = p.nu * p.dirs * p.nbb / 256;          // waves per workgroup: spread the tasks over the CUs first
+    nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
+    const int grid = p.nu * p.dirs * td_cdiv(p.nbb, nw);
+    for (int s = 0; s < p.L; ++s) hipLaunchKernelGGL(td_bptt_step_kernel, dim3(grid), dim3(64 * nw), 0, stream, q, carry, carry_dir, s);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight-gradient GEMM: C[m][col(n)] += sum_k A[m][k] B[n][k]   (bf16 operands with k contiguous, fp32 accumulation)
 //
 // d W = d a . [x ; h]^T over all L * batch columns: M x N of a few hundred to a few thousand, K in the tens to hundreds
@@ -1506,6 +1649,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
         const int n_src = l == N - 1 ? 1 : D;
         const size_t packT_dir = tg.hh_bytes + (l > 0 ? tg.ih_bytes : 0);
         const char *wT = (const char *)packT + tg.layer_off[l];
+        bool bias_in_sweep = g.nu <= 8;       // the sweeps of up to 8 unit blocks fold the bias gradients in (not the per-step form)
         {
             TdSweepParams q;
             TdBpttParams &p = q.b;
@@ -1532,6 +1676,10 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
                 cp.L = L; cp.nbb = t.nbb; cp.dirs = D; cp.out_frags = KT; cp.H = H;
                 for (int d = 0; d < 2; ++d) { cp.db_ih[d] = p.db_ih[d]; cp.db_hh[d] = p.db_hh[d]; }
                 rc = td_launch_bptt_cluster(cfg->gru, g, cp, stream);
+                if (rc != TD_OK) return rc;
+            } else if (mode != TD_LAYER_KERNEL_BATCH && td_use_step_launch(g.nu, t.nbb, D)) {
+                bias_in_sweep = false;
+                rc = td_launch_bptt_steps(q, (float *)(ws + t.dc[0]), (t.dc[1] - t.dc[0]) / sizeof(float), stream);
                 if (rc != TD_OK) return rc;
             } else if (g.nu <= 8) {
                 const size_t shm = (size_t)2 * 4 * g.kh * TD_FRAG_BYTES;
@@ -1607,7 +1755,7 @@ static int td_layers_backward(const td_rnn_config *cfg, const TdRnnGeom &g, cons
             for (int gate = 0; gate < G; gate += GM) {
                 const int slab_x = gate, slab_h = (cfg->gru && gate == 2) ? 3 : gate;
                 // biases (hidden sizes up to 256: folded into the sweep)
-                if (g.nu <= 8) continue;
+                if (bias_in_sweep) continue;
                 hipLaunchKernelGGL(td_bias_reduce_kernel, dim3(td_cdiv(GM * H, 4)), dim3(256), 0, stream,
                                    dapl + (size_t)slab_x * t.dapl_slab_elems, t.cols, GM * H, t.cols, gw[2] + gate * H,
                                    slab_h == slab_x ? gw[3] + gate * H : (float *)nullptr);

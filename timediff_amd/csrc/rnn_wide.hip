@@ -302,6 +302,214 @@ static int tdw_dispatch2(int gru, int save, const TdLayerParams &p, bool layer0,
     return save ? tdw_launch<NUW, NB, false, true, true, WAVES>(p, kx0, stream) : tdw_launch<NUW, NB, false, true, false, WAVES>(p, kx0, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same layer with ONE launch per time step (td_use_step_launch, rnn_geom.h): wide layers at small batches.
+// The persistent kernel above gives a batch block to one workgroup, which pulls the direction's whole weight stream
+// (6.2 MB at H = 512, 25 MB at H = 1024) through ONE CU's L2 port every step: 77 us per step at H = 512, whatever the
+// batch, with 32 of 256 CUs busy at batch 512.  Here a wave owns one (unit block, batch block[s], direction) of one
+// step: nu * dirs * batch blocks waves per launch spread over all CUs, each streaming only its unit block's slice
+// (388 KiB at H = 512); the waves of a workgroup work the SAME unit block for different batch blocks, so the slice
+// comes through the CU's L1 once, and a slice's workgroups sit on one XCD (indices a multiple of 8 apart).  h_{t-1}
+// is read from the layer's own output of the step before (a kernel boundary lies between its stores and these loads:
+// no hand-off protocol), the fp32 state from the same scratch as above.  A step costs a kernel boundary (4-5 us)
+// instead of a barrier, which is why the persistent form stays for batches that fill the chip.
+// Same bias / recurrent / input order of the MFMAs and the same gate sequence as the kernel above: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool L0, bool GRU, bool SAVE>
+__global__ __launch_bounds__(256, 1) void td_rnn_step_wide_kernel(TdLayerParams p, int kx0, int s, int nu) {
+    constexpr int NG = GRU ? 3 : 4, KC = 4, CH = KC * NG;
+    constexpr int D = NB == 1 ? 4 : 2;          // chunks in the ring (80 registers each at NB = 1)
+    const int KH = 2 * nu;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int slices = nu * p.dirs;
+    const int slice = blockIdx.x % slices, grp = blockIdx.x / slices;
+    const int u = slice % nu, dir = slice / nu;
+    const int ntile = (p.nbb + NB - 1) / NB, tile = grp * nw + wave;
+    if (tile >= ntile) return;                                  // (no barrier in this kernel)
+    int bbs[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bbs[n] = tile * NB + n < p.nbb ? tile * NB + n : p.nbb - 1;   // an odd count: the last block twice (same values)
+    const int KXF = L0 ? 0 : p.in_frags;
+    const int XFR0 = L0 ? 2 * kx0 : 0;
+    const int FU = 4 + (KH + (L0 ? XFR0 : KXF)) * NG;
+    const int l = dir ? p.L - 1 - s : s, lp = dir ? l + 1 : l - 1;
+
+    bf16x8 ones = {};
+    if (lane < 32) { ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f; }
+    const bf16x8 *wa = (const bf16x8 *)(p.wpacked + (size_t)dir * p.dir_stride) + lane + (size_t)u * FU * 64;
+    const bf16x8 *xp[NB], *hl[NB];
+    bf16x8 *op[NB];
+    float *stp[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        xp[n] = (const bf16x8 *)(p.xin + ((size_t)l * p.nbb + bbs[n]) * p.in_frags * TD_FRAG_BYTES) + lane;
+        hl[n] = (const bf16x8 *)(p.out + (((size_t)(s > 0 ? lp : l) * p.nbb + bbs[n]) * p.out_frags + dir * KH) * TD_FRAG_BYTES) + lane;
+        op[n] = (bf16x8 *)(p.out + (((size_t)l * p.nbb + bbs[n]) * p.out_frags + dir * KH) * TD_FRAG_BYTES) + lane;
+        stp[n] = p.state + (size_t)dir * p.state_dir_stride + ((size_t)bbs[n] * nu + u) * 1024 + lane * 16;
+    }
+    f32x4 cst[NB][4];
+    auto ldState = [&]() {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cst[n][q] = s > 0 ? *(const f32x4 *)(stp[n] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x16 acc[NB][4];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][g][r] = 0.f;
+    // A ring of D chunks (a chunk = KC k-steps = CH weight fragments + the B operands they meet), D - 1 of them in flight
+    // while one is multiplied: with a few waves per CU a chunk's 20 KiB take ~1 us to arrive from L2 and its 16 MFMAs
+    // 0.25 us.  The recurrent and the input k-steps are one stream of chunks (the weight fragments are contiguous, the B
+    // operand's source is selected by pointer); at s = 0 the recurrent chunks are skipped (h_{-1} = 0 adds exact zeros).
+    // Straight-line bodies: the loads past the last chunk re-read it instead of branching.
+    bf16x8 A[D][CH], B[D][NB][KC];
+    const int NH = KH / KC, NX = KXF / KC, NT = NH + NX;
+    auto issue = [&](int c, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int cc = c < NT ? c : NT - 1;
+        const bf16x8 *wp = wa + (size_t)(4 + cc * CH) * 64;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) A[j][i] = wp[i * 64];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const bf16x8 *bp = cc < NH ? hl[n] + (size_t)(KC * cc) * 64 : xp[n] + (size_t)(KC * (cc - NH)) * 64;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) B[j][n][k] = bp[k * 64];
+        }
+    };
+    auto mma = [&](auto recc, auto jc) {
+        constexpr bool rec = decltype(recc)::value;
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int ai = (GRU && g == 2 && rec) ? 3 : g;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    acc[n][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][k * NG + g], B[j][n][k], acc[n][ai], 0, 0, 0);
+            }
+    };
+    constexpr std::true_type REC{};
+    constexpr std::false_type INP{};
+    const int c0 = s > 0 ? 0 : NH;
+    tdw_static_for<D - 1>([&](auto jc) { issue(c0 + decltype(jc)::value, jc); });
+    ldState();
+    TDW_PIN();
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const bf16x8 wb = wa[f * 64];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[n][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, ones, acc[n][f], 0, 0, 0);
+    }
+#pragma unroll 1
+    for (int c = c0; c < NT; c += D) {
+        tdw_static_for<D>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            TDW_PIN(); issue(c + j + D - 1, std::integral_constant<int, (j + D - 1) % D>{}); TDW_PIN();
+            if (c + j < NT) {
+                if (GRU && c + j < NH) mma(REC, jc);
+                else mma(INP, jc);
+            }
+        });
+    }
+    if constexpr (L0) {
+        // first layer: W = Whi + Wlo, x = xhi + xlo in bf16, the three leading products (rnn_layer.h)
+        const bf16x8 *wp = wa + (size_t)(4 + KH * NG) * 64;
+        for (int kx = 0; kx < kx0; ++kx) {
+            bf16x8 xhi[NB], xlo[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) { xhi[n] = xp[n][(2 * kx) * 64]; xlo[n] = xp[n][(2 * kx + 1) * 64]; }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const bf16x8 whi = wp[(size_t)(2 * (kx * NG + g)) * 64], wlo = wp[(size_t)(2 * (kx * NG + g) + 1) * 64];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    acc[n][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo[n], acc[n][g], 0, 0, 0);
+                    acc[n][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi[n], acc[n][g], 0, 0, 0);
+                    acc[n][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi[n], acc[n][g], 0, 0, 0);
+                }
+            }
+        }
+    }
+    constexpr float P2L2E = TD_GATE_SCALE_TANH;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        if (n > 0 && bbs[n] == bbs[n - 1]) continue;      // the repeated last block: already done
+        float hv[16];
+        float sv[5][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float prev = cst[n][r >> 2][r & 3];
+            if constexpr (!GRU) {
+                const float e0 = __builtin_amdgcn_exp2f(acc[n][0][r]), e1 = __builtin_amdgcn_exp2f(acc[n][1][r]);
+                const float e2 = __builtin_amdgcn_exp2f(acc[n][2][r]), e3 = __builtin_amdgcn_exp2f(acc[n][3][r]);
+                const float ig = __builtin_amdgcn_rcpf(1.0f + e0), fg = __builtin_amdgcn_rcpf(1.0f + e1);
+                const float t2 = __builtin_amdgcn_rcpf(e2 + 1.0f), og = __builtin_amdgcn_rcpf(1.0f + e3);
+                const float gg = __builtin_fmaf(-2.0f, t2, 1.0f);
+                const float cv = __builtin_fmaf(fg, prev, ig * gg);
+                cst[n][r >> 2][r & 3] = cv;
+                float t5 = __builtin_amdgcn_exp2f(P2L2E * cv);
+                t5 = __builtin_amdgcn_rcpf(t5 + 1.0f);
+                hv[r] = og * __builtin_fmaf(-2.0f, t5, 1.0f);
+                if constexpr (SAVE) { sv[0][r] = ig; sv[1][r] = fg; sv[2][r] = gg; sv[3][r] = og; sv[4][r] = cv; }
+            } else {
+                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][0][r]));
+                const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][1][r]));
+                float t2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, acc[n][3][r], acc[n][2][r]));
+                t2 = __builtin_amdgcn_rcpf(t2 + 1.0f);
+                const float ng = __builtin_fmaf(-2.0f, t2, 1.0f);
+                const float h = __builtin_fmaf(zg, prev, (1.0f - zg) * ng);
+                cst[n][r >> 2][r & 3] = h;
+                hv[r] = h;
+                if constexpr (SAVE) { sv[0][r] = rg; sv[1][r] = zg; sv[2][r] = ng; sv[3][r] = acc[n][3][r] * (1.0f / P2L2E); sv[4][r] = h; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4 *)(stp[n] + 4 * q) = cst[n][q];
+        bf16x8 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h0[j] = (__bf16)hv[j]; h1[j] = (__bf16)hv[8 + j]; }
+        op[n][(2 * u) * 64] = h0;
+        op[n][(2 * u + 1) * 64] = h1;
+        if constexpr (SAVE) {
+            float *svb = p.save + (size_t)dir * p.save_dir_stride + ((((size_t)l * p.nbb + bbs[n]) * nu + u) * 5) * 1024 + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4 *)(svb + k * 1024 + 4 * q) = f32x4{sv[k][4 * q], sv[k][4 * q + 1], sv[k][4 * q + 2], sv[k][4 * q + 3]};
+        }
+    }
+}
+
+template <int NB, bool L0, bool GRU, bool SAVE>
+static int tdw_launch_steps(const TdLayerParams &p, int kx0, int nu, hipStream_t stream) {
+    const int ntile = td_cdiv(p.nbb, NB), tasks = nu * p.dirs * ntile;
+    int nw = tasks / 256;                         // waves per workgroup: spread the tasks over the CUs first
+    nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
+    const int ngrp = td_cdiv(ntile, nw);
+    for (int s = 0; s < p.L; ++s)
+        hipLaunchKernelGGL((td_rnn_step_wide_kernel<NB, L0, GRU, SAVE>), dim3(nu * p.dirs * ngrp), dim3(64 * nw), 0, stream, p, kx0, s, nu);
+    TD_LAUNCH_CHECK();
+    return TD_OK;
+}
+
+template <int NB>
+static int tdw_dispatch_steps(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, int nu, hipStream_t stream) {
+    if (layer0) {
+        if (!gru) return save ? tdw_launch_steps<NB, true, false, true>(p, kx0, nu, stream) : tdw_launch_steps<NB, true, false, false>(p, kx0, nu, stream);
+        return save ? tdw_launch_steps<NB, true, true, true>(p, kx0, nu, stream) : tdw_launch_steps<NB, true, true, false>(p, kx0, nu, stream);
+    }
+    if (!gru) return save ? tdw_launch_steps<NB, false, false, true>(p, kx0, nu, stream) : tdw_launch_steps<NB, false, false, false>(p, kx0, nu, stream);
+    return save ? tdw_launch_steps<NB, false, true, true>(p, kx0, nu, stream) : tdw_launch_steps<NB, false, true, false>(p, kx0, nu, stream);
+}
+
 // NUW: unit blocks per wave with four waves
 template <int NUW>
 static int tdw_dispatch(int gru, int save, const TdLayerParams &p, bool layer0, int kx0, hipStream_t stream) {
@@ -323,6 +531,13 @@ int td_launch_layer_wide(int gru, int save, int nu, const TdLayerParams &p, bool
     if (!layer0 && p.in_frags != p.dirs * 2 * nu) {
         td_set_error("wide recurrent layer: %d input fragments, expected %d", p.in_frags, p.dirs * 2 * nu);
         return TD_ERR_INVALID;
+    }
+    if (td_use_step_launch(nu, p.nbb, p.dirs)) {
+        // two batch blocks per wave (a weight fragment feeds two MFMAs) once one block per wave is more than two waves per
+        // CU: from there the launch is bound by the CUs' vector-memory ports (1.25 KiB per MFMA), not by MFMA issue
+        // (measured, H = 512: batch 512 5.4 ms per layer with one block against 6.5 with two; batch 2048 16.1 against 12.3)
+        if (nu * p.dirs * p.nbb > 512) return tdw_dispatch_steps<2>(gru, save, p, layer0, kx0, nu, stream);
+        return tdw_dispatch_steps<1>(gru, save, p, layer0, kx0, nu, stream);
     }
     switch (nu) {
         // small batches at H <= 256 (td_use_wide): one unit block per wave, as many waves as blocks
