@@ -1227,22 +1227,27 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
 // ([dir][bblk][u][64 lanes][16] fp32, the forward's state scratch) between launches.  Same order of the MFMAs and the
 // same gate-gradient arithmetic as the WIDE sweep above: bit-identical d a.
 // ---------------------------------------------------------------------------------------------
-#ifndef TD_BPTT_STEP_RING
-#define TD_BPTT_STEP_RING 24    // fragment pairs in flight per wave (48 KiB): the product is bound by L2 latency, not by its 128 MFMAs
-#endif
+// RING: fragment pairs in flight per wave (24 -> 48 KiB), a divisor of the product's nterm * kh pairs, so that the loop has
+// no branch: with one (a guarded MFMA, a guarded counter update) the compiler waits vmcnt(0) at every pair and the ring
+// degenerates to load -> wait -> MFMA, 190 cycles per pair (the WIDE sweep above still pays that).
+template <int RING>
 __global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, float *carry_buf, size_t carry_dir, int s) {
     const TdBpttParams &p = q.b;
     const int lane = threadIdx.x & 63, hf = lane >> 5, m = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const int slices = p.nu * p.dirs;
-    const int slice = blockIdx.x % slices, grp = blockIdx.x / slices;
-    const int u = slice % p.nu, d = slice / p.nu;
-    const int bblk = grp * nw + wave;
-    if (bblk >= p.nbb) return;                       // (no barrier in this kernel)
+    // Workgroups go to the XCDs round-robin by index, and after a kernel boundary an XCD's L2 is cold: what a step reads comes
+    // from the Infinity Cache once per XCD that touches it.  An XCD therefore works ONE direction and every G-th unit block
+    // of it (G = 8 / dirs XCDs per direction) for all batch blocks: it pulls nu / G slices of W_hh^T and that direction's d a
+    // (2.5 MB per step at H = 512, batch 512) instead of slices of both directions and all of d a (4.5 MB).
+    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int G = 8 / p.dirs, ngrp = (p.nbb + nw - 1) / nw;
+    const int d = p.dirs == 2 ? xcd / 4 : 0;
+    const int u = xcd % G + G * (slot / ngrp);
+    const int bblk = (slot % ngrp) * nw + wave;
+    if (u >= p.nu || bblk >= p.nbb) return;          // (no barrier in this kernel)
     const size_t stage_bytes = (size_t)4 * p.kh * TD_FRAG_BYTES;
     const size_t cols = (size_t)p.L * p.nbb * 32;
     const int hpad = p.kh * 16;
-    const unsigned slabs = (unsigned)q.slab[0] | (unsigned)q.slab[1] << 4 | (unsigned)q.slab[2] << 8 | (unsigned)q.slab[3] << 12;
     const int pos = p.L - 1 - s;                     // position in the direction's forward order
     const int l = d ? p.L - 1 - pos : pos;
     const int lprev = d ? l + 1 : l - 1;             // the step processed before l in the forward pass
@@ -1250,62 +1255,83 @@ __global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, f
     const bool has_prev = pos > 0;
     f32x4 dh[4], carry[4];
     float *cp = carry_buf + (size_t)d * carry_dir + (((size_t)bblk * p.nu + u) * 64 + lane) * 16;
+    // Everything the gate-gradient arithmetic reads -- the saved activations, c_{t-1}, the carry, the gradient from above --
+    // is requested here, ahead of the product: 36 KiB per wave whose latency the product's MFMAs hide (left where they are
+    // used, the loads came in 28 dependent groups, each waited for with vmcnt(0): 5 us of a 16 us step).
+    const f32x4 *sv = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16);
+    const f32x4 *svp = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16);
+    f32x4 S[5][4], PV[4];
+    bf16x8 GA[2], GB[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int qn = 0; qn < 5; ++qn) S[qn][k] = sv[256 * qn + k];
+        PV[k] = svp[k];
+        carry[k] = *(const f32x4 *)(cp + 4 * k);
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx < p.n_src ? sidx : 0] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
+        GA[sidx] = gp[0]; GB[sidx] = gp[64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef TD_BSTEP_NO_PRODUCT
+    if (false) {
+#else
     if (s > 0) {
+#endif
         // d h_t[this unit block] = W_hh^T x d a_{t+1}: both operands from L2, the loads RING fragment pairs ahead of their MFMA
         const bf16x8 *wp = (const bf16x8 *)(q.wt + (size_t)d * q.wt_dir + (size_t)u * q.nterm * p.kh * TD_FRAG_BYTES) + lane;
         const char *dab = p.daf + (size_t)d * p.daf_dir + ((size_t)lnext * p.nbb + bblk) * stage_bytes;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        constexpr int RING = TD_BPTT_STEP_RING;
-        const int total = q.nterm * p.kh;
-        auto bfrag = [&](int idx) {
-            const int term = idx / p.kh, ks = idx - term * p.kh;
-            const int sl = (int)((slabs >> (4 * term)) & 15u);
-            return *((const bf16x8 *)(dab + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
+        const int total = q.nterm * p.kh;            // a multiple of RING (td_launch_bptt_steps)
+        // pair i: W_hh^T fragment i of the unit block against d a fragment i, or i + gap from the third term on (the GRU's
+        // slabs r, z, n_h: td_launch_bptt_steps checks that the slab map has this form).  A handful of scalar instructions
+        // per pair: with (term, k-step) bookkeeping the pair cost 30 instructions = 150 issue cycles against the MFMA's 32.
+        const int jump = 2 * p.kh, gap = (q.slab[2] - 2) * p.kh;
+        int li = 0;
+        const bf16x8 *dabl = (const bf16x8 *)dab + lane;
+        auto load_next = [&](bf16x8 &a, bf16x8 &b) {
+            const int bi = li + (li >= jump ? gap : 0);
+            a = wp[(size_t)li * 64];
+            b = dabl[(size_t)bi * 64];
+            li = min(li + 1, total - 1);             // the loads past the last pair re-read it
         };
         bf16x8 ra[RING], rb[RING];
 #pragma unroll
-        for (int j = 0; j < RING; ++j) {
-            const int idx = j < total ? j : total - 1;
-            ra[j] = wp[(size_t)idx * 64];
-            rb[j] = bfrag(idx);
-        }
+        for (int j = 0; j < RING; ++j) load_next(ra[j], rb[j]);
         __builtin_amdgcn_sched_barrier(0);
         for (int i0 = 0; i0 < total; i0 += RING) {
 #pragma unroll
             for (int j = 0; j < RING; ++j) {
-                if (i0 + j < total) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[j], rb[j], acc, 0, 0, 0);
-                const int nx = i0 + j + RING < total ? i0 + j + RING : total - 1;
-                ra[j] = wp[(size_t)nx * 64];
-                rb[j] = bfrag(nx);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[j], rb[j], acc, 0, 0, 0);
+                load_next(ra[j], rb[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r >> 2][r & 3] = acc[r];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) carry[k] = *(const f32x4 *)(cp + 4 * k);
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { dh[k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int k = 0; k < 4; ++k) { dh[k] = f32x4{0.f, 0.f, 0.f, 0.f}; carry[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }   // (the scratch holds the last sweep's)
     }
-    for (int sidx = 0; sidx < p.n_src; ++sidx) {
-        const bf16x8 *gp = (const bf16x8 *)(p.gsrc[sidx] + (((size_t)l * p.nbb + bblk) * p.out_frags + d * p.kh + 2 * u) * TD_FRAG_BYTES) + lane;
-        const bf16x8 a = gp[0], b = gp[64];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { dh[j >> 2][j & 3] += (float)a[j]; dh[2 + (j >> 2)][j & 3] += (float)b[j]; }
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        if (sidx < p.n_src) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dh[j >> 2][j & 3] += (float)GA[sidx][j]; dh[2 + (j >> 2)][j & 3] += (float)GB[sidx][j]; }
+        }
     }
-    const f32x4 *sv = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)l * p.nbb + bblk) * p.nu + u) * 5) * 1024 + lane * 16);
-    const f32x4 *svp = (const f32x4 *)(p.save + (size_t)d * p.save_dir + ((((size_t)(has_prev ? lprev : l) * p.nbb + bblk) * p.nu + u) * 5 + 4) * 1024 + lane * 16);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float da[4][8];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int k = 2 * half + kk;
-            const f32x4 s0 = sv[k], s1 = sv[256 + k], s2 = sv[512 + k], s3 = sv[768 + k], s4 = sv[1024 + k];
-            const f32x4 pv = has_prev ? svp[k] : f32x4{0.f, 0.f, 0.f, 0.f};   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+            const f32x4 s0 = S[0][k], s1 = S[1][k], s2 = S[2][k], s3 = S[3][k], s4 = S[4][k];
+            const f32x4 pv = has_prev ? PV[k] : f32x4{0.f, 0.f, 0.f, 0.f};   // c_{t-1} (LSTM) / h_{t-1} (GRU)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * kk + e;
@@ -1337,12 +1363,14 @@ __global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, f
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = (__bf16)da[gi][j];
             *((bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
+#ifndef TD_BSTEP_NO_DAPL      // (diagnostic builds only)
             __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int unit = 32 * u + (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * hf;
                 pl[(size_t)unit * cols] = a[j];
             }
+#endif
         }
     }
     if (s + 1 < p.L) {
@@ -1355,8 +1383,15 @@ static int td_launch_bptt_steps(const TdSweepParams &q, float *carry, size_t car
     const TdBpttParams &p = q.b;
     int nw = p.nu * p.dirs * p.nbb / 256;          // waves per workgroup: spread the tasks over the CUs first
     nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
-    const int grid = p.nu * p.dirs * td_cdiv(p.nbb, nw);
-    for (int s = 0; s < p.L; ++s) hipLaunchKernelGGL(td_bptt_step_kernel, dim3(grid), dim3(64 * nw), 0, stream, q, carry, carry_dir, s);
+    const int grid = 8 * td_cdiv(p.nu, 8 / p.dirs) * td_cdiv(p.nbb, nw);
+    const int total = q.nterm * p.kh;
+    for (int term = 0; term < q.nterm; ++term)
+        TD_REQUIRE(q.slab[term] == term + (term >= 2 ? q.slab[2] - 2 : 0) && q.slab[2] >= 2, "per-step sweep: unexpected gate-slab map");
+    for (int s = 0; s < p.L; ++s) {
+        if (total % 24 == 0) hipLaunchKernelGGL(td_bptt_step_kernel<24>, dim3(grid), dim3(64 * nw), 0, stream, q, carry, carry_dir, s);
+        else if (total % 16 == 0) hipLaunchKernelGGL(td_bptt_step_kernel<16>, dim3(grid), dim3(64 * nw), 0, stream, q, carry, carry_dir, s);
+        else hipLaunchKernelGGL(td_bptt_step_kernel<8>, dim3(grid), dim3(64 * nw), 0, stream, q, carry, carry_dir, s);
+    }
     TD_LAUNCH_CHECK();
     return TD_OK;
 }

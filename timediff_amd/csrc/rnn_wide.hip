@@ -308,8 +308,8 @@ static int tdw_dispatch2(int gru, int save, const TdLayerParams &p, bool layer0,
 // (6.2 MB at H = 512, 25 MB at H = 1024) through ONE CU's L2 port every step: 77 us per step at H = 512, whatever the
 // batch, with 32 of 256 CUs busy at batch 512.  Here a wave owns one (unit block, batch block[s], direction) of one
 // step: nu * dirs * batch blocks waves per launch spread over all CUs, each streaming only its unit block's slice
-// (388 KiB at H = 512); the waves of a workgroup work the SAME unit block for different batch blocks, so the slice
-// comes through the CU's L1 once, and a slice's workgroups sit on one XCD (indices a multiple of 8 apart).  h_{t-1}
+// (388 KiB at H = 512); the waves of a workgroup work the SAME unit block for different batch blocks, and a slice's
+// workgroups sit on one XCD (see the index arithmetic at the top of the kernel).  h_{t-1}
 // is read from the layer's own output of the step before (a kernel boundary lies between its stores and these loads:
 // no hand-off protocol), the fp32 state from the same scratch as above.  A step costs a kernel boundary (4-5 us)
 // instead of a barrier, which is why the persistent form stays for batches that fill the chip.
@@ -322,11 +322,15 @@ __global__ __launch_bounds__(256, 1) void td_rnn_step_wide_kernel(TdLayerParams 
     const int KH = 2 * nu;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
-    const int slices = nu * p.dirs;
-    const int slice = blockIdx.x % slices, grp = blockIdx.x / slices;
-    const int u = slice % nu, dir = slice / nu;
-    const int ntile = (p.nbb + NB - 1) / NB, tile = grp * nw + wave;
-    if (tile >= ntile) return;                                  // (no barrier in this kernel)
+    // Workgroups go to the XCDs round-robin by index, and after a kernel boundary an XCD's L2 is cold: what a step reads comes
+    // from the Infinity Cache once per XCD that touches it.  An XCD therefore works ONE direction and every G-th unit block
+    // of it (G = 8 / dirs XCDs per direction) for all batch blocks: nu / G weight slices + that direction's h_{t-1} and x_t.
+    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int G = 8 / p.dirs, ntile = (p.nbb + NB - 1) / NB, ngrp = (ntile + nw - 1) / nw;
+    const int dir = p.dirs == 2 ? xcd / 4 : 0;
+    const int u = xcd % G + G * (slot / ngrp);
+    const int tile = (slot % ngrp) * nw + wave;
+    if (u >= nu || tile >= ntile) return;                       // (no barrier in this kernel)
     int bbs[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) bbs[n] = tile * NB + n < p.nbb ? tile * NB + n : p.nbb - 1;   // an odd count: the last block twice (same values)
@@ -495,7 +499,7 @@ static int tdw_launch_steps(const TdLayerParams &p, int kx0, int nu, hipStream_t
     nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
     const int ngrp = td_cdiv(ntile, nw);
     for (int s = 0; s < p.L; ++s)
-        hipLaunchKernelGGL((td_rnn_step_wide_kernel<NB, L0, GRU, SAVE>), dim3(nu * p.dirs * ngrp), dim3(64 * nw), 0, stream, p, kx0, s, nu);
+        hipLaunchKernelGGL((td_rnn_step_wide_kernel<NB, L0, GRU, SAVE>), dim3(8 * td_cdiv(nu, 8 / p.dirs) * ngrp), dim3(64 * nw), 0, stream, p, kx0, s, nu);
     TD_LAUNCH_CHECK();
     return TD_OK;
 }
