@@ -1164,29 +1164,29 @@ __global__ __launch_bounds__(512) void td_bptt_sweep_kernel(TdSweepParams q) {
                     // both operands come from L2 (2 KiB per MFMA): the loads run RING fragment pairs ahead of their MFMA,
                     // in a pinned order (left to the scheduler, each pair is loaded right before its use and the sweep
                     // spends its time in L2 latency)
+                    // No branch inside the loop (the pair count is a multiple of RING: kh is a multiple of 8 above 8 unit
+                    // blocks) and a handful of scalar instructions per pair: with a guarded MFMA and an index / kh per load
+                    // the compiler waited vmcnt(0) at every pair and a pair cost 190 issue cycles (td_bptt_step_kernel).
                     constexpr int RING = UPW > 2 ? 4 : 8;
                     const int total = q.nterm * p.kh;
-                    auto bfrag = [&](int idx) {
-                        const int term = idx / p.kh, ks = idx - term * p.kh;
-                        const int sl = (int)((slabs >> (4 * term)) & 15u);
-                        if constexpr (LDSB) return *((const bf16x8 *)(sm + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
-                        else return *((const bf16x8 *)(dab + ((size_t)sl * p.kh + ks) * TD_FRAG_BYTES) + lane);
+                    const int jump = 2 * p.kh, gap = (q.slab[2] - 2) * p.kh;     // slab map 0, 1, 2 + g, 3 + g (td_layers_backward)
+                    const bf16x8 *bsrc = (const bf16x8 *)(LDSB ? sm : dab) + lane;
+                    int li = 0;
+                    auto load_next = [&](bf16x8 &a, bf16x8 &b) {
+                        const int bi = li + (li >= jump ? gap : 0);
+                        a = wp[(size_t)li * 64];
+                        b = bsrc[(size_t)bi * 64];
+                        li = min(li + 1, total - 1);             // the loads past the last pair re-read it
                     };
                     bf16x8 ra[RING], rb[RING];
 #pragma unroll
-                    for (int j = 0; j < RING; ++j) {
-                        const int idx = j < total ? j : total - 1;
-                        ra[j] = wp[(size_t)idx * 64];
-                        rb[j] = bfrag(idx);
-                    }
+                    for (int j = 0; j < RING; ++j) load_next(ra[j], rb[j]);
                     __builtin_amdgcn_sched_barrier(0);
                     for (int i0 = 0; i0 < total; i0 += RING) {
 #pragma unroll
                         for (int j = 0; j < RING; ++j) {
-                            if (i0 + j < total) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[j], rb[j], acc, 0, 0, 0);
-                            const int nx = i0 + j + RING < total ? i0 + j + RING : total - 1;   // the tail re-reads the last pair
-                            ra[j] = wp[(size_t)nx * 64];
-                            rb[j] = bfrag(nx);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[j], rb[j], acc, 0, 0, 0);
+                            load_next(ra[j], rb[j]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
