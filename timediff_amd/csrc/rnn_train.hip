@@ -1275,11 +1275,7 @@ __global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, f
         GA[sidx] = gp[0]; GB[sidx] = gp[64];
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef TD_BSTEP_NO_PRODUCT
-    if (false) {
-#else
     if (s > 0) {
-#endif
         // d h_t[this unit block] = W_hh^T x d a_{t+1}: both operands from L2, the loads RING fragment pairs ahead of their MFMA
         const bf16x8 *wp = (const bf16x8 *)(q.wt + (size_t)d * q.wt_dir + (size_t)u * q.nterm * p.kh * TD_FRAG_BYTES) + lane;
         const char *dab = p.daf + (size_t)d * p.daf_dir + ((size_t)lnext * p.nbb + bblk) * stage_bytes;
@@ -1363,14 +1359,12 @@ __global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, f
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = (__bf16)da[gi][j];
             *((bf16x8 *)(p.daf + (size_t)d * p.daf_dir + ((((size_t)l * p.nbb + bblk) * 4 + gi) * p.kh + 2 * u + half) * TD_FRAG_BYTES) + lane) = a;
-#ifndef TD_BSTEP_NO_DAPL      // (diagnostic builds only)
             __bf16 *pl = p.dapl + (size_t)d * p.dapl_dir + (size_t)gi * hpad * cols + (size_t)l * p.nbb * 32 + bblk * 32 + m;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int unit = 32 * u + (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * hf;
                 pl[(size_t)unit * cols] = a[j];
             }
-#endif
         }
     }
     if (s + 1 < p.L) {
