@@ -1238,7 +1238,8 @@ __global__ __launch_bounds__(256, 1) void td_bptt_step_kernel(TdSweepParams q, f
     // Workgroups go to the XCDs round-robin by index, and after a kernel boundary an XCD's L2 is cold: what a step reads comes
     // from the Infinity Cache once per XCD that touches it.  An XCD therefore works ONE direction and every G-th unit block
     // of it (G = 8 / dirs XCDs per direction) for all batch blocks: it pulls nu / G slices of W_hh^T and that direction's d a
-    // (2.5 MB per step at H = 512, batch 512) instead of slices of both directions and all of d a (4.5 MB).
+    // (2.5 MB per step at H = 512, batch 512) instead of slices of both directions and all of d a (4.5 MB).  (Measured at that
+    // shape: no difference against the plain (unit block, direction) order -- the step is not bound there; kept for H = 1024.)
     const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int G = 8 / p.dirs, ngrp = (p.nbb + nw - 1) / nw;
     const int d = p.dirs == 2 ? xcd / 4 : 0;
