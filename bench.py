@@ -183,7 +183,10 @@ def _family_name(lib, et, seqs, L):
     from timediff_amd import _lib
     den = et.model.model._kernels or et.model.model.kernels()
     fam = lib.td_rnn_layer_kernel_choice(C.byref(den.cfg), seqs, L)
-    return {_lib.LAYER_KERNEL_BATCH: "batch-block", _lib.LAYER_KERNEL_UNITS: "unit-split", _lib.LAYER_KERNEL_CLUSTER: "cluster"}.get(fam, str(fam))
+    name = {_lib.LAYER_KERNEL_BATCH: "batch-block", _lib.LAYER_KERNEL_UNITS: "unit-split", _lib.LAYER_KERNEL_CLUSTER: "cluster"}.get(fam, str(fam))
+    if lib.td_rnn_step_launch_choice(C.byref(den.cfg), seqs, L) == 1:
+        name += ", one launch per time step"
+    return name
 
 
 def train_probe(dev, cols, L, H, N, T, batch, ga, steps, warmup, fuse=True):
@@ -426,6 +429,10 @@ def main():
             train = {"reference_batch": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 5),
                      "reference_batch_looped": train_probe(dev, cols, L, H, N, T, args.train_batch, 2, args.train_steps, 5, fuse=False),
                      "large_batch": train_probe(dev, cols, L, H, N, T, 2048, 1, 12, 4)}      # (warm-up > ETDiff.graph_warmup: the capture is not timed)
+            # BASELINE.json configs[4]'s per-GPU shape (wide-hidden BRNN, 512 sequences per GPU and optimizer step): reported beside
+            # the metric's own configurations, not part of `value`
+            torch.cuda.empty_cache()
+            train["wide_hidden"] = train_probe(dev, cols, L, 512, N, T, 512, 1, 10, 4)
         fl = denoiser_flops_per_seq(C_io, H, N, D, L) * T
         result = {
             "metric": "synthetic patient sequences/sec (full T-step reverse chain)", "value": value,

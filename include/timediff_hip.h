@@ -367,6 +367,8 @@ TD_API int td_set_side_gemm(int32_t on);
  * Bit-identical results either way.  No counterpart in the reference. */
 enum { TD_STEP_LAUNCH_AUTO = 0, TD_STEP_LAUNCH_OFF = 1, TD_STEP_LAUNCH_ON = 2 };
 TD_API int td_set_step_launch(int32_t mode);
+/* 1 where a launch of `batch` sequences would run that way under the current knobs, 0 where not, -1 on a bad configuration. */
+TD_API int td_rnn_step_launch_choice(const td_rnn_config *cfg, int32_t batch, int32_t seq_len);
 
 /* No counterpart in the reference.  The cluster-persistent kernels (small batches at hidden 193..256; the one-workgroup form
  * at hidden <= 96 has no hand-off between workgroups and cannot raise this) need every workgroup of a launch resident at once.  Where the device cannot give that (shared with another process, CU mask) a bounded poll

@@ -183,4 +183,6 @@ def test_step_launch_equals_persistent_kernels(H, layers, dirs, gru, C, n_num, B
             assert torch.equal(a[key], b[key]), key
     step_launch(_lib.STEP_LAUNCH_AUTO)
     want = _lib.STEP_LAUNCH_ON if H > 256 and -(-B // 32) * dirs <= 128 else _lib.STEP_LAUNCH_OFF
+    import ctypes as C
+    assert _lib.lib().td_rnn_step_launch_choice(C.byref(den.cfg), B, L) == (1 if want == _lib.STEP_LAUNCH_ON else 0)
     np.testing.assert_array_equal(den.forward(cu(x, dev), cu(t, dev)).cpu().numpy(), out[want]["y"].cpu().numpy())

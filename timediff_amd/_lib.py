@@ -102,6 +102,7 @@ _SIGS = {
     "td_clip_adam_ema_rec": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "td_set_layer_kernel": (C.c_int, [_I]),
     "td_rnn_layer_kernel_choice": (C.c_int, [C.POINTER(RnnConfig), _I, _I]),
+    "td_rnn_step_launch_choice": (C.c_int, [C.POINTER(RnnConfig), _I, _I]),
     "td_cls_workspace_bytes": (C.c_size_t, [C.POINTER(RnnConfig), _I, _I]),
     "td_cls_forward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "td_cls_backward": (C.c_int, [C.POINTER(RnnConfig), _P, _P, _P, _P, _P, _I, _I, _P, C.POINTER(_P), _P, _P, _P]),

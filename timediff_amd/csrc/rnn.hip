@@ -78,6 +78,14 @@ extern "C" int td_rnn_layer_kernel_choice(const td_rnn_config *cfg, int32_t batc
     return td_use_wide(g, nbb) ? TD_LAYER_KERNEL_UNITS : TD_LAYER_KERNEL_BATCH;
 }
 
+// 1 where the unit-split family would run this launch as one launch per time step (td_set_step_launch), else 0
+extern "C" int td_rnn_step_launch_choice(const td_rnn_config *cfg, int32_t batch, int32_t seq_len) {
+    TdRnnGeom g;
+    if (td_rnn_geom(cfg, &g) != TD_OK || batch <= 0 || seq_len <= 0) return -1;
+    const int nbb = td_cdiv(batch, TD_WAVE_BATCH);
+    return !td_use_cluster(g, nbb, seq_len) && td_use_wide(g, nbb) && td_use_step_launch(g.nu, nbb, g.dirs) ? 1 : 0;
+}
+
 // workspace: [x0 fragments][act A][act B][wide layers: state, dirs regions]
 static void td_ws_layout(const TdRnnGeom &g, int batch, int L, size_t *x0_bytes, size_t *act_bytes) {
     size_t nbb = (size_t)td_cdiv(batch, TD_WAVE_BATCH);
