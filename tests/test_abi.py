@@ -40,6 +40,37 @@ def test_argument_validation_without_gpu():
     assert L.td_rnn_packed_bytes(ctypes.byref(cfg)) == 0
 
 
+def test_kernel_selection_knobs_without_gpu():
+    """The launch-form queries are host arithmetic: which recurrent-layer family AUTO takes and whether it launches step by
+    step (td_set_step_launch), per width and batch; unknown knob values are refused."""
+    from timediff_amd import _lib
+    L = _lib.lib()
+
+    def choice(hidden, batch, seq_len=272):
+        cfg = _lib.RnnConfig(c_in=14, hidden=hidden, c_out=14, layers=3, dirs=2, gru=0, embed_dim=64, time_dim=256)
+        return L.td_rnn_layer_kernel_choice(ctypes.byref(cfg), batch, seq_len), L.td_rnn_step_launch_choice(ctypes.byref(cfg), batch, seq_len)
+
+    assert L.td_set_step_launch(7) != 0 and b"td_set_step_launch" in L.td_last_error()
+    assert L.td_set_layer_kernel(9) != 0
+    try:
+        assert choice(256, 64) == (_lib.LAYER_KERNEL_CLUSTER, 0)           # the reference's training batch
+        assert choice(256, 16384) == (_lib.LAYER_KERNEL_BATCH, 0)          # bench.py's sampler batch
+        assert choice(92, 256) == (_lib.LAYER_KERNEL_CLUSTER, 0)           # MIMIC-III width: the one-workgroup form
+        assert choice(512, 512) == (_lib.LAYER_KERNEL_UNITS, 1)            # configs[4] per GPU: one launch per time step
+        assert choice(1024, 2048) == (_lib.LAYER_KERNEL_UNITS, 1)          # 128 (batch block, direction) pairs: still per step
+        assert choice(512, 8192) == (_lib.LAYER_KERNEL_UNITS, 0)           # configs[3]: the persistent kernel
+        assert L.td_set_step_launch(_lib.STEP_LAUNCH_OFF) == 0
+        assert choice(512, 512) == (_lib.LAYER_KERNEL_UNITS, 0)
+        assert L.td_set_step_launch(_lib.STEP_LAUNCH_ON) == 0
+        assert choice(512, 8192) == (_lib.LAYER_KERNEL_UNITS, 1)
+        assert choice(192, 64) == (_lib.LAYER_KERNEL_UNITS, 0)             # 6 unit blocks: not whole groups of four
+        assert choice(128, 64) == (_lib.LAYER_KERNEL_UNITS, 1)
+        assert choice(320, 64) == (_lib.LAYER_KERNEL_UNITS, 1)             # 10 unit blocks run as 12
+    finally:
+        assert L.td_set_step_launch(_lib.STEP_LAUNCH_AUTO) == 0
+    assert choice(0, 64) == (-1, -1)
+
+
 def _diff_cfg(_lib, **over):
     """An eICU-shaped td_diffusion_config whose `tables` pointer is a dummy: every call below must be
     rejected before anything dereferences it."""
